@@ -1,0 +1,277 @@
+/*
+ * rt_mi355x.h — C-ABI of the MI355X-native render core (librt_mi355x.so).
+ *
+ * Drop-in boundary for the hot path of alexsykes8/raytracer: the body of `render_scene_func`
+ * (reference Code/main.cpp:229-359) — camera rays -> BVH closest hit -> Whitted/Blinn-Phong shading ->
+ * tone map -> RGB8 framebuffer.  The reference exposes no FFI of its own; every entry point below cites the
+ * reference interface it replaces.  Plain pointers and sizes only: no STL, no exceptions, no torch types.
+ *
+ * Conventions: every int-returning function returns 0 on success and a negative RT_ERR_* code on failure;
+ * rt_last_error() then returns a thread-local description (the reference reports errors as C++ exceptions caught
+ * in main, Code/main.cpp:562-565).  No ownership is transferred across the ABI: the library copies what it
+ * needs during the call.  One host thread may call the rt_render / rt_scene functions on a given scene at a time.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK                 0
+#define RT_ERR_INVALID       -1   /* bad argument / malformed description */
+#define RT_ERR_IO            -2   /* file could not be opened / parsed */
+#define RT_ERR_DEVICE        -3   /* HIP runtime error, or no usable GPU */
+#define RT_ERR_NOT_INIT      -4
+#define RT_ERR_LIMIT         -5   /* a documented capacity limit was exceeded */
+
+/* ------------------------------------------------------------------------------------------------
+ * Scene description (POD).  Mirrors what a fully constructed reference `Scene` holds
+ * (Code/utilities/scene.h:18-34) before its BVH wrap: camera, lights, shapes with their matrices and
+ * materials, textures, optional HDR environment.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Shape kinds == the scene-file block names (Code/utilities/scene.cpp:188-246). */
+enum {
+    RT_SHAPE_SPHERE = 0,          /* Code/shapes/sphere.cpp        */
+    RT_SHAPE_PLANE = 1,           /* Code/shapes/plane.cpp  (quad = two triangles) */
+    RT_SHAPE_CUBE = 2,            /* Code/shapes/cube.cpp          */
+    RT_SHAPE_COMPLEX_SPHERE = 3,  /* Code/shapes/complex_sphere.cpp (displaced, ray-marched) */
+    RT_SHAPE_COMPLEX_CUBE = 4,    /* Code/shapes/complex_cube.cpp  */
+    RT_SHAPE_COMPLEX_PLANE = 5    /* Code/shapes/complex_plane.cpp */
+};
+
+/* Camera constructor arguments, Code/environment/camera.cpp:27-38 (sensor_height is overwritten by
+ * sensor_width/aspect exactly as the reference does, camera.cpp:49-55). */
+typedef struct RtCamera {
+    double location[3];
+    double gaze_direction[3];
+    double up_vector[3];
+    double focal_length;      /* mm */
+    double sensor_width;      /* mm */
+    double sensor_height;     /* mm (ignored, see above) */
+    int32_t resolution_x;
+    int32_t resolution_y;
+    double f_stop;            /* scene.cpp:137 default 99999 */
+    double focal_distance;    /* scene.cpp:138 default 10    */
+} RtCamera;
+
+/* Code/environment/light.h:13-28 */
+typedef struct RtLight {
+    double position[3];
+    double intensity[3];
+    double radius;
+} RtLight;
+
+/* Code/shapes/material.h:17-51.  texture / bump_map index RtSceneDesc.textures, -1 = none.
+ * is_metal = (Material::type == "metal"), tracer.h:216. */
+typedef struct RtMaterial {
+    double ambient[3];
+    double diffuse[3];
+    double specular[3];
+    double shininess;
+    double reflectivity;
+    double transparency;
+    double refractive_index;
+    int32_t texture;
+    int32_t bump_map;
+    int32_t is_metal;
+    int32_t reserved;
+} RtMaterial;
+
+/* One scene object.  transform / inv_transform are the row-major 4x4 matrices the reference hands to the shape
+ * constructors (scene.cpp:285-290: T*Rz*Ry*Rx*S and its cofactor inverse); planes use `corners` instead
+ * (scene.cpp:380-381).  max_displacement is what the Complex* constructors read from
+ * advanced.displacement_strength (complex_sphere.cpp:17, complex_cube.cpp:21, complex_plane.cpp:20). */
+typedef struct RtShape {
+    int32_t type;             /* RT_SHAPE_*            */
+    int32_t material;         /* index into materials  */
+    double transform[16];
+    double inv_transform[16];
+    double corners[12];       /* c0,c1,c2,c3 (planes)  */
+    double velocity[3];
+    double max_displacement;
+} RtShape;
+
+/* RGB8 image, row 0 = top (Code/utilities/Image.h:46-47). */
+typedef struct RtTexture {
+    int32_t width;
+    int32_t height;
+    const uint8_t* rgb;       /* width*height*3 bytes  */
+} RtTexture;
+
+/* HDR environment (Code/environment/HDRImage.h:41): float RGB, row 0 = first row of the PFM payload.
+ * present=1 with width==0 reproduces "HDR_BACKGROUND given but the file failed to load => black environment"
+ * (scene.cpp:172, HDRImage.cpp:114). */
+typedef struct RtEnvMap {
+    int32_t present;
+    int32_t width;
+    int32_t height;
+    int32_t reserved;
+    const float* rgb;
+} RtEnvMap;
+
+typedef struct RtSceneDesc {
+    RtCamera camera;
+    int32_t n_lights;
+    int32_t n_shapes;
+    int32_t n_materials;
+    int32_t n_textures;
+    const RtLight* lights;
+    const RtShape* shapes;
+    const RtMaterial* materials;
+    const RtTexture* textures;
+    RtEnvMap env;
+    double shutter_time;      /* Scene ctor argument (scene.h:16): sizes the motion-blur AABBs and the ray times */
+} RtSceneDesc;
+
+/* ------------------------------------------------------------------------------------------------
+ * Render parameters == the remaining Scene ctor arguments (scene.h:16), the Config keys the hot loop reads
+ * (Code/config.json) and main's per-render locals (main.cpp:246-249, :68).
+ * ---------------------------------------------------------------------------------------------- */
+enum { RT_TONEMAP_NONE = 0, RT_TONEMAP_REINHARD = 1, RT_TONEMAP_ACES = 2, RT_TONEMAP_FILMIC = 3 }; /* main.cpp:68 */
+enum {
+    RT_RNG_D0 = 0,      /* deterministic: every uniform 0.5, ball/disk samples 0 (oracle mode "d0") */
+    RT_RNG_SEEDED = 1   /* counter-based generator keyed by (seed, pixel, sample, draw index)     */
+};
+
+typedef struct RtRenderParams {
+    int32_t samples_per_pixel;   /* --aa / settings.samples_per_pixel, main.cpp:54,113           */
+    int32_t max_depth;           /* MAX_DEPTH, settings.max_bounces default 10, main.cpp:249      */
+    int32_t max_bounces;         /* Scene::m_max_bounces, default 5, scene.cpp:96                 */
+    int32_t tonemap;             /* RT_TONEMAP_*                                                  */
+    int32_t shadows;             /* --shadows                                                     */
+    int32_t fresnel;             /* --fresnel                                                     */
+    int32_t normals;             /* --normals                                                     */
+    int32_t use_bvh;             /* 0 == --no-bvh: linear list in scene-file order                */
+    int32_t glossy_samples;      /* 0 unless --glossy (then render.glossy_samples), main.cpp:152  */
+    int32_t shadow_samples;      /* render.shadow_samples default 4, scene.cpp:94                 */
+    int32_t ray_march_steps;     /* advanced.ray_march_steps default 64, complex_*.cpp            */
+    int32_t rng_mode;            /* RT_RNG_*                                                      */
+    double exposure;             /* image.exposure / --exposure                                   */
+    double eps_scene;            /* advanced.epsilon default 1e-4  (scene.cpp:95, tracer.h:152)   */
+    double eps_triangle;         /* advanced.epsilon default 0.001 (plane.cpp:83)                 */
+    double eps_march;            /* advanced.epsilon default 0.001 (complex_*.cpp)                */
+    double eps_shadow;           /* advanced.epsilon default 1e-4  (shading.h:83)                 */
+    double step_multiplier;      /* advanced.step_multiplier default 0.8 (complex_plane.cpp:167)  */
+    double background[3];        /* background.{r,g,b} defaults .5 .7 1 (tracer.h:290-292)        */
+    double ambient_light[3];     /* lighting.{r,g,b} defaults .15 .15 .25 (shading.h:142-144)     */
+    uint64_t seed;               /* RT_RNG_SEEDED only                                            */
+    /* Image partition for multi-GPU rendering (no counterpart in the reference, which shares one Image between
+     * OpenMP threads, main.cpp:242,279): the frame is cut into row tiles of `tile_rows` rows; tile k belongs to
+     * part (k % part_count).  part_count<=1 renders the whole frame. */
+    int32_t tile_rows;
+    int32_t part_index;
+    int32_t part_count;
+    int32_t reserved;
+} RtRenderParams;
+
+typedef struct RtStats {
+    uint64_t rays;            /* closest-hit queries == reference world.intersect calls (tracer.h:156, shading.h:45) */
+    uint64_t nodes_visited;   /* BVH node boxes tested   (filled only when collect_counters != 0) */
+    uint64_t prims_tested;    /* primitive intersection tests (same)                              */
+    double kernel_ms;         /* device time of the render kernel (hipEvent), 0 if not measured    */
+    double total_ms;          /* wall time of the call incl. copies                                */
+} RtStats;
+
+typedef struct rt_scene_s* rt_scene_t;
+typedef struct rt_config_s* rt_config_t;
+typedef struct rt_scene_file_s* rt_scene_file_t;
+
+/* ---- device lifecycle ------------------------------------------------------------------------- */
+
+/* Select the GPU this process renders on and create its stream.  One process per GPU (torchrun / RCCL ranks);
+ * device_id < 0 keeps the current HIP device.  Fails with RT_ERR_DEVICE when no gfx950-compatible device exists:
+ * there is no CPU fallback.  (The reference has no device: OpenMP threads, main.cpp:257-264.) */
+int rt_init(int device_id);
+void rt_shutdown(void);
+const char* rt_last_error(void);
+
+/* ---- scene ------------------------------------------------------------------------------------- */
+
+/* Build the device scene: camera basis (camera.cpp:74-86), per-shape inverse transforms, quads as two
+ * triangles (plane.cpp:49-74), world AABBs (transformed_shape.h:42-77, plane.cpp:11-46, complex_*::getBoundingBox),
+ * the median-split BVH (bvh.cpp:32-92) flattened to 64-byte nodes, materials, textures, environment; upload all
+ * of it to HBM.  Replaces `Scene::Scene` step scene.cpp:102-121 + the object graph the hot loop walks. */
+int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out);
+void rt_scene_destroy(rt_scene_t scene);
+
+/* Host-only BVH facts (no GPU needed): for tests and for the roofline's bytes-per-node figure. */
+typedef struct RtBvhInfo {
+    int32_t n_nodes;
+    int32_t n_prims;
+    int32_t max_depth;
+    int32_t node_bytes;
+    double root_min[3];
+    double root_max[3];
+} RtBvhInfo;
+int rt_scene_bvh_info(rt_scene_t scene, RtBvhInfo* out);
+/* Same build without any device work: returns the facts and, when order_out != NULL (n_shapes ints), the
+ * depth-first leaf order of the shapes — the order the reference's BVHNode::intersect visits them. */
+int rt_bvh_build_host(const RtSceneDesc* desc, RtBvhInfo* info_out, int32_t* order_out);
+
+/* ---- render ------------------------------------------------------------------------------------ */
+
+/* Whole-frame render into a caller-owned host buffer rgb8_out[H*W*3], row-major, top row first — the bytes of
+ * `Image::m_pixel_data` after main.cpp:281-322 (Image.h:46-47).  With part_count>1 only the rows of tiles
+ * owned by part_index are written; the rest of the buffer is left untouched.  stats may be NULL. */
+int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats);
+
+/* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t, NULL = the library's
+ * stream): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice
+ * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to 4 uint64 (rays, nodes, prims,
+ * reserved) that the kernel adds into; collect_counters!=0 additionally counts node/primitive tests. */
+int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
+                     int collect_counters, void* hip_stream);
+
+/* Number of image rows owned by (part_index, part_count) for a frame of `height` rows cut into `tile_rows` tiles. */
+int rt_part_rows(int height, int tile_rows, int part_index, int part_count);
+/* Scatter a compact part slice (as written by rt_render_device) into a full row-major frame (host memory). */
+int rt_part_scatter(const uint8_t* slice, uint8_t* frame, int width, int height, int tile_rows, int part_index,
+                    int part_count);
+
+/* ---- host side kept from the reference: config.json, scene files, images ---------------------- */
+
+/* Code/config.cpp:7-103 (`Config::load/getInt/getDouble/getBool`).  A missing file is not an error for the
+ * reference (warning + defaults); rt_config_load returns RT_ERR_IO but still yields an empty, usable config. */
+int rt_config_load(const char* path, rt_config_t* out);
+int rt_config_parse(const char* text, rt_config_t* out);
+int rt_config_get_int(rt_config_t cfg, const char* key, int default_value);
+double rt_config_get_double(rt_config_t cfg, const char* key, double default_value);
+int rt_config_get_bool(rt_config_t cfg, const char* key, int default_value);
+void rt_config_destroy(rt_config_t cfg);
+
+/* Fill params with what main.cpp + Scene would use for this config and no command-line flags
+ * (main.cpp:52-68,249; scene.cpp:94-96; call-site defaults for missing keys). */
+int rt_params_from_config(rt_config_t cfg, RtRenderParams* out);
+
+/* `Scene::parseSceneFile` (scene.cpp:124-546) for the Blender-ASCII format.  texture_root replaces the
+ * reference's cwd-relative "../" prefix (scene.cpp:171,270): a texture named X is loaded from texture_root/X.
+ * cfg supplies advanced.displacement_strength; shutter_time is the Scene ctor argument. */
+int rt_scene_file_load(const char* scene_path, const char* texture_root, rt_config_t cfg, double shutter_time,
+                       rt_scene_file_t* out);
+int rt_scene_file_parse(const char* scene_text, const char* texture_root, rt_config_t cfg, double shutter_time,
+                        rt_scene_file_t* out);
+const RtSceneDesc* rt_scene_file_desc(rt_scene_file_t f);
+void rt_scene_file_destroy(rt_scene_file_t f);
+
+/* Compose shape matrices exactly as scene.cpp:277-287 does (T*Rz*Ry*Rx*S, cofactor inverse, matrix4x4.cpp):
+ * trs = n x 9 doubles (translation xyz, rotation_euler_radians xyz, scale xyz); fills transform/inv_transform of
+ * shapes[i].  For building large synthetic scenes without going through text. */
+int rt_shapes_from_trs(int n, const double* trs, RtShape* shapes);
+
+/* `Image::write` (Image.cpp:170-188): "P6\nW H\n255\n" + bytes.  `Image::read` (Image.cpp:84-167): P3/P6. */
+int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgb);
+int rt_read_ppm(const char* path, int* width, int* height, uint8_t** rgb_out /* free with rt_free */);
+/* `HDRImage::load` (HDRImage.cpp:22-109): "PF" portable float map. */
+int rt_read_pfm(const char* path, int* width, int* height, float** rgb_out /* free with rt_free */);
+void rt_free(void* p);
+
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -1,0 +1,51 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes wrapper of the CPU oracle (oracle/_build/librt_oracle.so, built from
+oracle/rt_oracle.cpp by `make -C oracle port`).  Imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "librt_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("build the oracle first: make -C oracle port")
+        _lib = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        _lib.rt_oracle_render_rows.restype = i32
+        _lib.rt_oracle_render_rows.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        _lib.rt_oracle_render.restype = i32
+        _lib.rt_oracle_render.argtypes = [vp, vp, vp, i32, vp]
+        _lib.rt_oracle_render_float.restype = i32
+        _lib.rt_oracle_render_float.argtypes = [vp, vp, vp, i32]
+    return _lib
+
+
+def render(scene_desc, params, threads=0, counters=False, rows=None):
+    """scene_desc: object with desc_ptr()/width/height (raytracer_amd.SceneFile / SceneBuilder); params: RtRenderParams.
+    rows=(begin, end, step) renders a subset of rows (others stay 0).  Returns img or (img, [rays, boxes, prims])."""
+    h, w = scene_desc.height, scene_desc.width
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    cnt = (C.c_uint64 * 3)()
+    b, e, s = rows if rows is not None else (0, h, 1)
+    rc = lib().rt_oracle_render_rows(C.cast(scene_desc.desc_ptr(), C.c_void_p), C.cast(C.pointer(params), C.c_void_p),
+                                     img.ctypes.data, b, e, s, threads, C.cast(cnt, C.c_void_p) if counters else None)
+    if rc != 0:
+        raise RuntimeError("oracle render failed: %d" % rc)
+    return (img, [int(c) for c in cnt]) if counters else img
+
+
+def render_float(scene_desc, params, threads=0):
+    h, w = scene_desc.height, scene_desc.width
+    img = np.zeros((h, w, 3), dtype=np.float64)
+    rc = lib().rt_oracle_render_float(C.cast(scene_desc.desc_ptr(), C.c_void_p), C.cast(C.pointer(params), C.c_void_p),
+                                      img.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("oracle render failed: %d" % rc)
+    return img

@@ -1,0 +1,575 @@
+// C-ABI of librt_mi355x.so (include/rt_mi355x.h): scene upload, render launch, and the host-side pieces kept
+// from the reference (config.json, scene files, PPM/PFM).  No CPU rendering path exists in this library: every
+// rt_render* call runs the HIP kernel of render_kernel.hip or fails with RT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "device_types.h"
+#include "host_bvh.h"
+#include "host_config.h"
+#include "host_image.h"
+#include "host_math.h"
+#include "host_scene.h"
+#include "render_kernel.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceState {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t* d_counters = nullptr;  // 4 x u64
+};
+DeviceState g_dev;
+
+template <typename T>
+int upload(const std::vector<T>& v, T** out) {
+    *out = nullptr;
+    if (v.empty()) return RT_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(out), v.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+}  // namespace
+
+struct rt_scene_s {
+    HostBvh bvh;
+    int n_shapes = 0;
+    int width = 0, height = 0;
+    DScene d{};                       // device view (pointers are device pointers)
+    std::vector<void*> allocations;   // everything to hipFree
+    uint8_t* d_frame = nullptr;       // scratch framebuffer for rt_render
+    size_t d_frame_bytes = 0;
+    bool on_device = false;
+};
+struct rt_config_s {
+    ConfigData cfg;
+};
+struct rt_scene_file_s {
+    std::unique_ptr<SceneFile> scene;
+};
+
+static int validate_desc(const RtSceneDesc* d) {
+    if (!d) return fail(RT_ERR_INVALID, "scene description is NULL");
+    if (d->camera.resolution_x <= 0 || d->camera.resolution_y <= 0)
+        return fail(RT_ERR_INVALID, "Image width and height must be positive.");  // Image.cpp:75-77
+    if (d->n_shapes < 0 || d->n_lights < 0 || d->n_materials < 0 || d->n_textures < 0) return fail(RT_ERR_INVALID, "negative count");
+    if ((d->n_shapes && !d->shapes) || (d->n_lights && !d->lights) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures))
+        return fail(RT_ERR_INVALID, "array pointer is NULL");
+    for (int i = 0; i < d->n_shapes; ++i) {
+        const RtShape& s = d->shapes[i];
+        if (s.type < RT_SHAPE_SPHERE || s.type > RT_SHAPE_COMPLEX_PLANE) return fail(RT_ERR_INVALID, "shape " + std::to_string(i) + ": unknown type");
+        if (s.material < 0 || s.material >= d->n_materials) return fail(RT_ERR_INVALID, "shape " + std::to_string(i) + ": material index out of range");
+        // The device keeps rows 0..2 and element [3][3] of the inverse: shapes are affine (scene.cpp:285 only composes T,R,S).
+        if (s.type != RT_SHAPE_PLANE && (s.inv_transform[12] != 0.0 || s.inv_transform[13] != 0.0 || s.inv_transform[14] != 0.0))
+            return fail(RT_ERR_INVALID, "shape " + std::to_string(i) + ": projective transforms are not supported");
+    }
+    for (int i = 0; i < d->n_materials; ++i) {
+        const RtMaterial& m = d->materials[i];
+        if (m.texture >= d->n_textures || m.bump_map >= d->n_textures) return fail(RT_ERR_INVALID, "material " + std::to_string(i) + ": texture index out of range");
+    }
+    for (int i = 0; i < d->n_textures; ++i)
+        if (d->textures[i].width <= 0 || d->textures[i].height <= 0 || !d->textures[i].rgb) return fail(RT_ERR_INVALID, "texture " + std::to_string(i) + " is empty");
+    if (d->env.present && d->env.rgb && (d->env.width <= 0 || d->env.height <= 0)) return fail(RT_ERR_INVALID, "environment map has no size");
+    return RT_OK;
+}
+
+// Host-side derivation of the device arrays from the description + hierarchy.
+struct HostArrays {
+    std::vector<DPrim> prims;
+    std::vector<int32_t> file_order;
+    std::vector<DXform> xforms;
+    std::vector<DQuad> quads;
+    std::vector<DMaterial> materials;
+    std::vector<DLight> lights;
+    int32_t features = 0;
+    DCamera cam{};
+};
+
+static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
+    HostArrays h;
+    h.prims.resize(d.n_shapes);
+    h.file_order.resize(d.n_shapes);
+    for (int k = 0; k < d.n_shapes; ++k) {
+        int fi = bvh.order[k];
+        const RtShape& s = d.shapes[fi];
+        DPrim& p = h.prims[k];
+        p.type = s.type;
+        p.material = s.material;
+        p.file_index = fi;
+        h.file_order[fi] = k;
+        if (s.type == RT_SHAPE_PLANE) {
+            // plane.cpp:49-74
+            DQuad q{};
+            V3 c0(s.corners), c1(s.corners + 3), c2(s.corners + 6), c3(s.corners + 9);
+            V3 e1 = c1 - c0, e2 = c2 - c0;
+            store(q.v0, c0); store(q.e1, e1); store(q.e2, e2);
+            store(q.w0, c1); store(q.f1, c3 - c1); store(q.f2, c2 - c1);
+            store(q.n, normalize(cross(e1, e2)));
+            std::memcpy(q.vel, s.velocity, sizeof(q.vel));
+            p.data = static_cast<int32_t>(h.quads.size());
+            h.quads.push_back(q);
+            h.features |= RT_FEAT_QUAD;
+        } else {
+            DXform x{};
+            std::memcpy(x.inv, s.inv_transform, 12 * sizeof(double));
+            x.inv33 = s.inv_transform[15];
+            std::memcpy(x.vel, s.velocity, sizeof(x.vel));
+            x.disp = s.max_displacement;
+            p.data = static_cast<int32_t>(h.xforms.size());
+            h.xforms.push_back(x);
+            h.features |= (s.type == RT_SHAPE_SPHERE) ? RT_FEAT_SPHERE : (s.type == RT_SHAPE_CUBE) ? RT_FEAT_CUBE : RT_FEAT_COMPLEX;
+        }
+    }
+    h.materials.resize(d.n_materials);
+    for (int i = 0; i < d.n_materials; ++i) {
+        const RtMaterial& m = d.materials[i];
+        DMaterial& o = h.materials[i];
+        std::memcpy(o.ambient, m.ambient, 24);
+        std::memcpy(o.diffuse, m.diffuse, 24);
+        std::memcpy(o.specular, m.specular, 24);
+        o.shininess = m.shininess;
+        o.reflectivity = m.reflectivity;
+        o.transparency = m.transparency;
+        o.ior = m.refractive_index;
+        o.texture = m.texture < 0 ? -1 : m.texture;
+        o.bump = m.bump_map < 0 ? -1 : m.bump_map;
+        o.is_metal = m.is_metal ? 1 : 0;
+        o.pad = 0;
+        if (o.texture >= 0 || o.bump >= 0) h.features |= RT_FEAT_TEXTURE;
+    }
+    h.lights.resize(d.n_lights);
+    for (int i = 0; i < d.n_lights; ++i) {
+        std::memcpy(h.lights[i].pos, d.lights[i].position, 24);
+        std::memcpy(h.lights[i].intensity, d.lights[i].intensity, 24);
+        h.lights[i].radius = d.lights[i].radius;
+    }
+    if (d.env.present) h.features |= RT_FEAT_ENV;
+    // camera.cpp:27-86
+    const RtCamera& c = d.camera;
+    DCamera& cam = h.cam;
+    std::memcpy(cam.location, c.location, 24);
+    V3 w = normalize(V3(c.gaze_direction));
+    V3 u = normalize(cross(V3(c.up_vector), w));
+    V3 v = cross(u, w);
+    store(cam.u, u); store(cam.v, v); store(cam.w, w);
+    cam.focal_length = c.focal_length;
+    cam.sensor_width = c.sensor_width;
+    double aspect = static_cast<double>(c.resolution_x) / static_cast<double>(c.resolution_y);
+    cam.sensor_height = c.sensor_width / aspect;
+    double focal_m = c.focal_length / 1000.0;
+    cam.aperture_radius = (c.f_stop > 0) ? focal_m / (2.0 * c.f_stop) : 0.0;
+    cam.focal_distance = c.focal_distance;
+    cam.res_x = c.resolution_x;
+    cam.res_y = c.resolution_y;
+    return h;
+}
+
+extern "C" {
+
+const char* rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+const char* rt_last_error(void) { return g_error.c_str(); }
+void rt_free(void* p) { std::free(p); }
+
+int rt_init(int device_id) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RT_ERR_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+    if (device_id >= count) return fail(RT_ERR_INVALID, "device_id out of range");
+    if (device_id >= 0) HIP_TRY(hipSetDevice(device_id));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (g_dev.ready && g_dev.device == dev) return RT_OK;
+    if (g_dev.ready) rt_shutdown();
+    g_dev.device = dev;
+    HIP_TRY(hipStreamCreateWithFlags(&g_dev.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g_dev.ev0));
+    HIP_TRY(hipEventCreate(&g_dev.ev1));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_dev.d_counters), 4 * sizeof(uint64_t)));
+    g_dev.ready = true;
+    return RT_OK;
+}
+
+void rt_shutdown(void) {
+    if (!g_dev.ready) return;
+    (void)hipSetDevice(g_dev.device);
+    if (g_dev.stream) (void)hipStreamDestroy(g_dev.stream);
+    if (g_dev.ev0) (void)hipEventDestroy(g_dev.ev0);
+    if (g_dev.ev1) (void)hipEventDestroy(g_dev.ev1);
+    if (g_dev.d_counters) (void)hipFree(g_dev.d_counters);
+    g_dev = DeviceState();
+}
+
+int rt_bvh_build_host(const RtSceneDesc* desc, RtBvhInfo* info, int32_t* order_out) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    HostBvh b = build_bvh(*desc);
+    if (info) {
+        info->n_nodes = static_cast<int32_t>(b.nodes.size());
+        info->n_prims = desc->n_shapes;
+        info->max_depth = b.max_depth;
+        info->node_bytes = kNodeBytes;
+        store(info->root_min, b.root_box.lo);
+        store(info->root_max, b.root_box.hi);
+    }
+    if (order_out)
+        for (int i = 0; i < desc->n_shapes; ++i) order_out[i] = b.order[i];
+    return RT_OK;
+}
+
+int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    HIP_TRY(hipSetDevice(g_dev.device));
+
+    auto sc = std::make_unique<rt_scene_s>();
+    sc->n_shapes = desc->n_shapes;
+    sc->width = desc->camera.resolution_x;
+    sc->height = desc->camera.resolution_y;
+    sc->bvh = build_bvh(*desc);
+    // Interior levels + the leaf level must fit the per-lane traversal stack (one deferred sibling per level).
+    if (sc->bvh.max_depth + 1 > kTravStackDepth)
+        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->bvh.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + ")");
+    HostArrays h = derive_arrays(*desc, sc->bvh);
+
+    DScene& d = sc->d;
+    auto track = [&](void* p) { if (p) sc->allocations.push_back(p); };
+    auto cleanup_fail = [&](int code) {
+        for (void* p : sc->allocations) (void)hipFree(p);
+        return code;
+    };
+    DNode* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
+    if ((rc = upload(sc->bvh.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
+    if ((rc = upload(h.prims, &d_prims))) return cleanup_fail(rc); track(d_prims);
+    if ((rc = upload(h.file_order, &d_forder))) return cleanup_fail(rc); track(d_forder);
+    if ((rc = upload(h.xforms, &d_x))) return cleanup_fail(rc); track(d_x);
+    if ((rc = upload(h.quads, &d_q))) return cleanup_fail(rc); track(d_q);
+    if ((rc = upload(h.materials, &d_m))) return cleanup_fail(rc); track(d_m);
+    if ((rc = upload(h.lights, &d_l))) return cleanup_fail(rc); track(d_l);
+    std::vector<DTexture> tex(desc->n_textures);
+    for (int i = 0; i < desc->n_textures; ++i) {
+        const RtTexture& t = desc->textures[i];
+        size_t bytes = static_cast<size_t>(t.width) * t.height * 3;
+        uint8_t* p = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+        if (e == hipSuccess) { track(p); e = hipMemcpy(p, t.rgb, bytes, hipMemcpyHostToDevice); }
+        if (e != hipSuccess) return cleanup_fail(fail(RT_ERR_DEVICE, std::string("texture upload: ") + hipGetErrorString(e)));
+        tex[i] = DTexture{p, t.width, t.height};
+    }
+    DTexture* d_tex;
+    if ((rc = upload(tex, &d_tex))) return cleanup_fail(rc); track(d_tex);
+    float* d_env = nullptr;
+    if (desc->env.present && desc->env.rgb && desc->env.width > 0) {
+        size_t bytes = static_cast<size_t>(desc->env.width) * desc->env.height * 3 * sizeof(float);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_env), bytes);
+        if (e == hipSuccess) { track(d_env); e = hipMemcpy(d_env, desc->env.rgb, bytes, hipMemcpyHostToDevice); }
+        if (e != hipSuccess) return cleanup_fail(fail(RT_ERR_DEVICE, std::string("environment upload: ") + hipGetErrorString(e)));
+    }
+    d.nodes = d_nodes; d.prims = d_prims; d.file_order = d_forder; d.xforms = d_x; d.quads = d_q;
+    d.materials = d_m; d.textures = d_tex; d.lights = d_l; d.env = d_env;
+    d.env_present = desc->env.present ? 1 : 0;
+    d.env_w = d_env ? desc->env.width : 0;
+    d.env_h = d_env ? desc->env.height : 0;
+    d.n_prims = desc->n_shapes;
+    d.n_nodes = static_cast<int32_t>(sc->bvh.nodes.size());
+    d.n_lights = desc->n_lights;
+    d.root_ref = sc->bvh.root_ref;
+    d.features = h.features;
+    store(d.root_lo, sc->bvh.root_box.lo);
+    store(d.root_hi, sc->bvh.root_box.hi);
+    d.shutter_time = desc->shutter_time;
+    d.cam = h.cam;
+    sc->on_device = true;
+    *out = sc.release();
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene_t scene) {
+    if (!scene) return;
+    if (scene->on_device && g_dev.ready) {
+        (void)hipSetDevice(g_dev.device);
+        for (void* p : scene->allocations) (void)hipFree(p);
+        if (scene->d_frame) (void)hipFree(scene->d_frame);
+    }
+    delete scene;
+}
+
+int rt_scene_bvh_info(rt_scene_t scene, RtBvhInfo* out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    out->n_nodes = static_cast<int32_t>(scene->bvh.nodes.size());
+    out->n_prims = scene->n_shapes;
+    out->max_depth = scene->bvh.max_depth;
+    out->node_bytes = kNodeBytes;
+    store(out->root_min, scene->bvh.root_box.lo);
+    store(out->root_max, scene->bvh.root_box.hi);
+    return RT_OK;
+}
+
+int rt_part_rows(int height, int tile_rows, int part_index, int part_count) {
+    if (height <= 0 || tile_rows <= 0) return 0;
+    if (part_count <= 1) return height;
+    if (part_index < 0 || part_index >= part_count) return 0;
+    int n_tiles = (height + tile_rows - 1) / tile_rows, rows = 0;
+    for (int k = part_index; k < n_tiles; k += part_count) rows += std::min(tile_rows, height - k * tile_rows);
+    return rows;
+}
+
+int rt_part_scatter(const uint8_t* slice, uint8_t* frame, int width, int height, int tile_rows, int part_index, int part_count) {
+    if (!slice || !frame || width <= 0 || height <= 0 || tile_rows <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    if (part_count <= 1) { std::memcpy(frame, slice, static_cast<size_t>(width) * height * 3); return RT_OK; }
+    if (part_index < 0 || part_index >= part_count) return fail(RT_ERR_INVALID, "part_index out of range");
+    int n_tiles = (height + tile_rows - 1) / tile_rows;
+    size_t row_bytes = static_cast<size_t>(width) * 3, src_row = 0;
+    for (int k = part_index; k < n_tiles; k += part_count) {
+        int y0 = k * tile_rows, rows = std::min(tile_rows, height - y0);
+        std::memcpy(frame + y0 * row_bytes, slice + src_row * row_bytes, rows * row_bytes);
+        src_row += rows;
+    }
+    return RT_OK;
+}
+
+static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, DParams* o) {
+    if (!scene || !p) return fail(RT_ERR_INVALID, "NULL argument");
+    if (p->samples_per_pixel <= 0) return fail(RT_ERR_INVALID, "samples_per_pixel must be >= 1");
+    if (p->tonemap < 0 || p->tonemap > 3) return fail(RT_ERR_INVALID, "unknown tonemap mode");
+    if (p->rng_mode != RT_RNG_D0 && p->rng_mode != RT_RNG_SEEDED) return fail(RT_ERR_INVALID, "unknown rng_mode");
+    if (p->shadows && p->shadow_samples <= 0) return fail(RT_ERR_INVALID, "shadow_samples must be >= 1 when shadows are on");
+    if (p->glossy_samples < 0) return fail(RT_ERR_INVALID, "glossy_samples must be >= 0");
+    // Pending-ray stack bound: the first hit may queue glossy_samples + 1 rays, every deeper level at most one more.
+    if (std::max(p->max_depth, 0) + p->glossy_samples + 2 > kRayStackDepth)
+        return fail(RT_ERR_LIMIT, "max_depth + glossy_samples exceeds the pending-ray stack (" + std::to_string(kRayStackDepth) + ")");
+    int parts = p->part_count <= 1 ? 1 : p->part_count;
+    int tile = p->tile_rows > 0 ? p->tile_rows : 8;
+    if (parts > 1 && (p->part_index < 0 || p->part_index >= parts)) return fail(RT_ERR_INVALID, "part_index out of range");
+    DParams d{};
+    d.width = scene->width; d.height = scene->height;
+    d.spp = p->samples_per_pixel; d.max_depth = p->max_depth; d.max_bounces = p->max_bounces; d.tonemap = p->tonemap;
+    d.shadows = p->shadows != 0; d.fresnel = p->fresnel != 0; d.normals = p->normals != 0; d.use_bvh = p->use_bvh != 0;
+    d.glossy_samples = p->glossy_samples; d.shadow_samples = p->shadow_samples; d.march_steps = p->ray_march_steps; d.rng_mode = p->rng_mode;
+    d.tile_rows = tile; d.part_index = parts > 1 ? p->part_index : 0; d.part_count = parts;
+    d.part_rows = rt_part_rows(scene->height, tile, d.part_index, parts);
+    d.count_tests = collect ? 1 : 0;
+    d.exposure = p->exposure; d.eps_scene = p->eps_scene; d.eps_triangle = p->eps_triangle; d.eps_march = p->eps_march;
+    d.eps_shadow = p->eps_shadow; d.step_multiplier = p->step_multiplier;
+    std::memcpy(d.background, p->background, 24);
+    std::memcpy(d.ambient_light, p->ambient_light, 24);
+    d.seed = p->seed;
+    *o = d;
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters, int collect_counters, void* hip_stream) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!d_rgb8) return fail(RT_ERR_INVALID, "d_rgb8 is NULL");
+    DParams dp;
+    int rc = make_dparams(scene, params, collect_counters, &dp);
+    if (rc) return rc;
+    if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
+    if (dp.part_rows == 0) return RT_OK;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
+    hipError_t e = launch_render(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!scene || !params || !rgb8_out) return fail(RT_ERR_INVALID, "NULL argument");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(g_dev.device));
+    int parts = params->part_count <= 1 ? 1 : params->part_count;
+    int tile = params->tile_rows > 0 ? params->tile_rows : 8;
+    int rows = rt_part_rows(scene->height, tile, parts > 1 ? params->part_index : 0, parts);
+    size_t bytes = static_cast<size_t>(rows) * scene->width * 3;
+    if (scene->d_frame_bytes < bytes) {
+        if (scene->d_frame) (void)hipFree(scene->d_frame);
+        scene->d_frame = nullptr;
+        scene->d_frame_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame), bytes ? bytes : 1));
+        scene->d_frame_bytes = bytes;
+    }
+    HIP_TRY(hipMemsetAsync(g_dev.d_counters, 0, 4 * sizeof(uint64_t), g_dev.stream));
+    HIP_TRY(hipEventRecord(g_dev.ev0, g_dev.stream));
+    int rc = rt_render_device(scene, params, scene->d_frame, g_dev.d_counters, stats != nullptr, g_dev.stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g_dev.ev1, g_dev.stream));
+    std::vector<uint8_t> slice;
+    uint8_t* dst = rgb8_out;
+    if (parts > 1) { slice.resize(bytes); dst = slice.data(); }
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, scene->d_frame, bytes, hipMemcpyDeviceToHost, g_dev.stream));
+    uint64_t counters[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(counters, g_dev.d_counters, sizeof(counters), hipMemcpyDeviceToHost, g_dev.stream));
+    HIP_TRY(hipStreamSynchronize(g_dev.stream));
+    if (parts > 1 && bytes) {
+        rc = rt_part_scatter(slice.data(), rgb8_out, scene->width, scene->height, tile, params->part_index, parts);
+        if (rc) return rc;
+    }
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_dev.ev0, g_dev.ev1));
+        stats->rays = counters[0];
+        stats->nodes_visited = counters[1];
+        stats->prims_tested = counters[2];
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- config / scene files / images (host only)
+
+int rt_config_load(const char* path, rt_config_t* out) {
+    if (!path || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    auto c = new rt_config_s();
+    *out = c;
+    if (!c->cfg.load_file(path)) return fail(RT_ERR_IO, std::string("Warning: Could not open config file '") + path + "'. Using defaults.");
+    return RT_OK;
+}
+int rt_config_parse(const char* text, rt_config_t* out) {
+    if (!text || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    auto c = new rt_config_s();
+    c->cfg.parse_text(text);
+    *out = c;
+    return RT_OK;
+}
+int rt_config_get_int(rt_config_t cfg, const char* key, int def) { return (cfg && key) ? cfg->cfg.get_int(key, def) : def; }
+double rt_config_get_double(rt_config_t cfg, const char* key, double def) { return (cfg && key) ? cfg->cfg.get_double(key, def) : def; }
+int rt_config_get_bool(rt_config_t cfg, const char* key, int def) { return (cfg && key) ? (cfg->cfg.get_bool(key, def != 0) ? 1 : 0) : def; }
+void rt_config_destroy(rt_config_t cfg) { delete cfg; }
+
+int rt_params_from_config(rt_config_t cfg, RtRenderParams* o) {
+    if (!o) return fail(RT_ERR_INVALID, "NULL argument");
+    ConfigData empty;
+    const ConfigData& c = cfg ? cfg->cfg : empty;
+    std::memset(o, 0, sizeof(*o));
+    o->samples_per_pixel = c.get_int("settings.samples_per_pixel", 1);   // main.cpp:54
+    o->max_depth = c.get_int("settings.max_bounces", 10);                // main.cpp:249
+    o->max_bounces = c.get_int("settings.max_bounces", 5);               // scene.cpp:96
+    o->tonemap = RT_TONEMAP_NONE;
+    o->use_bvh = 1;
+    o->glossy_samples = 0;                                               // main.cpp:59
+    o->shadow_samples = c.get_int("render.shadow_samples", 4);           // scene.cpp:94
+    o->ray_march_steps = c.get_int("advanced.ray_march_steps", 64);      // complex_*.cpp
+    o->rng_mode = RT_RNG_SEEDED;
+    o->exposure = c.get_double("image.exposure", 1.0);                   // main.cpp:56
+    o->eps_scene = c.get_double("advanced.epsilon", 1e-4);               // scene.cpp:95
+    o->eps_triangle = c.get_double("advanced.epsilon", 0.001);           // plane.cpp:83
+    o->eps_march = c.get_double("advanced.epsilon", 0.001);              // complex_*.cpp
+    o->eps_shadow = c.get_double("advanced.epsilon", 1e-4);              // shading.h:83
+    o->step_multiplier = c.get_double("advanced.step_multiplier", 0.8);  // complex_plane.cpp:167
+    o->background[0] = c.get_double("background.r", 0.5);                // tracer.h:290-292
+    o->background[1] = c.get_double("background.g", 0.7);
+    o->background[2] = c.get_double("background.b", 1.0);
+    o->ambient_light[0] = c.get_double("lighting.r", 0.15);              // shading.h:142-144
+    o->ambient_light[1] = c.get_double("lighting.g", 0.15);
+    o->ambient_light[2] = c.get_double("lighting.b", 0.25);
+    o->seed = 1;
+    o->tile_rows = 8;
+    o->part_index = 0;
+    o->part_count = 1;
+    return RT_OK;
+}
+
+static int scene_file_finish(std::unique_ptr<SceneFile> s, rt_scene_file_t* out) {
+    auto f = new rt_scene_file_s();
+    f->scene = std::move(s);
+    *out = f;
+    return RT_OK;
+}
+int rt_scene_file_load(const char* path, const char* texture_root, rt_config_t cfg, double shutter_time, rt_scene_file_t* out) {
+    if (!path || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    ConfigData empty;
+    try {
+        return scene_file_finish(load_scene_file(path, texture_root ? texture_root : "", cfg ? cfg->cfg : empty, shutter_time), out);
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_IO, e.what());
+    }
+}
+int rt_scene_file_parse(const char* text, const char* texture_root, rt_config_t cfg, double shutter_time, rt_scene_file_t* out) {
+    if (!text || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    ConfigData empty;
+    try {
+        return scene_file_finish(parse_scene_text(text, texture_root ? texture_root : "", cfg ? cfg->cfg : empty, shutter_time), out);
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_IO, e.what());
+    }
+}
+const RtSceneDesc* rt_scene_file_desc(rt_scene_file_t f) { return f ? &f->scene->desc : nullptr; }
+void rt_scene_file_destroy(rt_scene_file_t f) { delete f; }
+
+int rt_shapes_from_trs(int n, const double* trs, RtShape* shapes) {
+    if (n < 0 || (n && (!trs || !shapes))) return fail(RT_ERR_INVALID, "bad argument");
+    try {
+        for (int i = 0; i < n; ++i) shape_set_trs(shapes[i], trs + i * 9, trs + i * 9 + 3, trs + i * 9 + 6);
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_INVALID, e.what());
+    }
+    return RT_OK;
+}
+
+int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {
+    if (!path || !rgb || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    try {
+        write_ppm(path, width, height, rgb);
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_IO, e.what());
+    }
+    return RT_OK;
+}
+int rt_read_ppm(const char* path, int* width, int* height, uint8_t** rgb_out) {
+    if (!path || !width || !height || !rgb_out) return fail(RT_ERR_INVALID, "NULL argument");
+    try {
+        Image8 img = read_ppm(path);
+        *width = img.width;
+        *height = img.height;
+        *rgb_out = static_cast<uint8_t*>(std::malloc(img.rgb.size()));
+        if (!*rgb_out) return fail(RT_ERR_LIMIT, "out of memory");
+        std::memcpy(*rgb_out, img.rgb.data(), img.rgb.size());
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_IO, e.what());
+    }
+    return RT_OK;
+}
+int rt_read_pfm(const char* path, int* width, int* height, float** rgb_out) {
+    if (!path || !width || !height || !rgb_out) return fail(RT_ERR_INVALID, "NULL argument");
+    ImageF img;
+    std::string why;
+    if (!read_pfm(path, img, &why)) return fail(RT_ERR_IO, why);
+    *width = img.width;
+    *height = img.height;
+    *rgb_out = static_cast<float*>(std::malloc(img.rgb.size() * sizeof(float)));
+    if (!*rgb_out) return fail(RT_ERR_LIMIT, "out of memory");
+    std::memcpy(*rgb_out, img.rgb.data(), img.rgb.size() * sizeof(float));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+#include "host_bvh.h"
+
+#include <algorithm>
+#include <limits>
+#include <numeric>
+
+namespace rt {
+
+static Box transformed_box(const RtShape& s, V3 lmin, V3 lmax, double shutter_time) {
+    const double inf = std::numeric_limits<double>::infinity();
+    M4 m = from_row_major(s.transform);
+    Box b{{inf, inf, inf}, {-inf, -inf, -inf}};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k)
+                grow(b, transform_point(m, V3(i ? lmax.x : lmin.x, j ? lmax.y : lmin.y, k ? lmax.z : lmin.z)));
+    V3 d = V3(s.velocity) * shutter_time;  // box at shutter open  U  box at shutter close
+    return combine(b, Box{b.lo + d, b.hi + d});
+}
+
+Box shape_bounds(const RtShape& s, double shutter_time) {
+    switch (s.type) {
+        case RT_SHAPE_SPHERE:
+        case RT_SHAPE_CUBE:
+            return transformed_box(s, V3(-1, -1, -1), V3(1, 1, 1), shutter_time);
+        case RT_SHAPE_COMPLEX_SPHERE:
+        case RT_SHAPE_COMPLEX_CUBE: {
+            double r = 1.0 + s.max_displacement;
+            return transformed_box(s, V3(-r, -r, -r), V3(r, r, r), shutter_time);
+        }
+        case RT_SHAPE_COMPLEX_PLANE: {
+            // complex_plane.cpp:41-60: per corner, the swept end point is added only when |velocity| > 1e-6.
+            // (The reference reads an uninitialised m_shutter_time there, complex_plane.cpp:13-21; the scene's
+            // shutter time is used here.)
+            const double inf = std::numeric_limits<double>::infinity();
+            double zb = s.max_displacement + 0.01;
+            M4 m = from_row_major(s.transform);
+            V3 vel(s.velocity);
+            bool moving = length(vel) > 1e-6;
+            Box b{{inf, inf, inf}, {-inf, -inf, -inf}};
+            for (int i = 0; i < 8; ++i) {
+                V3 p = transform_point(m, V3((i & 1) ? 1.0 : -1.0, (i & 2) ? 1.0 : -1.0, (i & 4) ? zb : -zb));
+                grow(b, p);
+                if (moving) grow(b, p + vel * shutter_time);
+            }
+            return b;
+        }
+        case RT_SHAPE_PLANE:
+        default: {
+            // plane.cpp:11-46: corners are re-derived from the stored edges, then padded by 1e-4.
+            V3 c0(s.corners), c1(s.corners + 3), c2(s.corners + 6), c3(s.corners + 9);
+            V3 v1 = c0 + (c1 - c0), v2 = c0 + (c2 - c0), v3 = c1 + (c3 - c1);
+            Box b{c0, c0};
+            grow(b, v1);
+            grow(b, v2);
+            grow(b, v3);
+            const double pad = 1e-4;
+            b.lo = b.lo - V3(pad, pad, pad);
+            b.hi = b.hi + V3(pad, pad, pad);
+            V3 d = V3(s.velocity) * shutter_time;
+            return combine(b, Box{b.lo + d, b.hi + d});
+        }
+    }
+}
+
+namespace {
+
+struct Builder {
+    const std::vector<Box>& boxes;
+    std::vector<V3> centre;          // (lo+hi)*0.5, the sort key of bvh.cpp:14-15
+    std::vector<int32_t> idx;        // working permutation of shape indices
+    HostBvh out;
+
+    struct Built {
+        int32_t ref;
+        Box box;
+        int32_t depth;
+    };
+
+    bool less_on(int axis, int32_t a, int32_t b) const { return centre[a][axis] < centre[b][axis]; }
+
+    // One reference BVHNode over idx[start, end).  Nodes whose two children are shapes become leaf references;
+    // everything else becomes a DNode carrying its children's boxes.
+    Built build(size_t start, size_t end) {
+        Box span = boxes[idx[start]];
+        for (size_t i = start + 1; i < end; ++i) span = combine(span, boxes[idx[i]]);
+        V3 ext = span.hi - span.lo;
+        int axis = 0;  // bvh.cpp:52-58: strict comparisons, x on ties
+        if (ext.y > ext.x && ext.y > ext.z) axis = 1;
+        else if (ext.z > ext.x && ext.z > ext.y) axis = 2;
+
+        size_t n = end - start;
+        if (n == 1) {  // left == right == the single shape
+            int32_t first = static_cast<int32_t>(out.order.size());
+            out.order.push_back(idx[start]);
+            return {make_leaf_ref(first, 1), boxes[idx[start]], 0};
+        }
+        if (n == 2) {  // ordered pair (bvh.cpp:67-75)
+            int32_t a = idx[start], b = idx[start + 1];
+            if (!less_on(axis, a, b)) std::swap(a, b);
+            int32_t first = static_cast<int32_t>(out.order.size());
+            out.order.push_back(a);
+            out.order.push_back(b);
+            return {make_leaf_ref(first, 2), combine(boxes[a], boxes[b]), 0};
+        }
+        size_t mid = start + n / 2;
+        std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end,
+                         [&](int32_t a, int32_t b) { return less_on(axis, a, b); });
+        int32_t me = static_cast<int32_t>(out.nodes.size());
+        out.nodes.emplace_back();
+        Built l = build(start, mid);
+        Built r = build(mid, end);
+        DNode& nd = out.nodes[me];
+        store(nd.lo[0], l.box.lo); store(nd.hi[0], l.box.hi);
+        store(nd.lo[1], r.box.lo); store(nd.hi[1], r.box.hi);
+        nd.child[0] = l.ref;
+        nd.child[1] = r.ref;
+        for (int& p : nd.pad) p = 0;
+        return {me, combine(l.box, r.box), 1 + std::max(l.depth, r.depth)};
+    }
+};
+
+}  // namespace
+
+HostBvh build_bvh(const RtSceneDesc& desc) {
+    std::vector<Box> boxes(desc.n_shapes);
+    for (int i = 0; i < desc.n_shapes; ++i) boxes[i] = shape_bounds(desc.shapes[i], desc.shutter_time);
+    Builder b{boxes, {}, {}, {}};
+    if (desc.n_shapes == 0) {
+        b.out.root_ref = make_leaf_ref(0, 1);
+        b.out.root_box = Box{};
+        return b.out;
+    }
+    b.centre.resize(desc.n_shapes);
+    for (int i = 0; i < desc.n_shapes; ++i) b.centre[i] = (boxes[i].lo + boxes[i].hi) * 0.5;
+    b.idx.resize(desc.n_shapes);
+    std::iota(b.idx.begin(), b.idx.end(), 0);
+    b.out.nodes.reserve(desc.n_shapes);
+    b.out.order.reserve(desc.n_shapes);
+    Builder::Built root = b.build(0, desc.n_shapes);
+    b.out.root_ref = root.ref;
+    b.out.root_box = root.box;
+    b.out.max_depth = root.depth;
+    return std::move(b.out);
+}
+
+}  // namespace rt

@@ -1,0 +1,27 @@
+// Host BVH construction: the reference's top-down median split (Code/acceleration/bvh.cpp:32-92) over the
+// reference's per-shape world boxes, flattened for the device (device_types.h: DNode).
+#pragma once
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "device_types.h"
+#include "host_math.h"
+
+namespace rt {
+
+struct HostBvh {
+    std::vector<DNode> nodes;      // interior nodes, node 0 = root (empty when the scene has <= 2 shapes)
+    std::vector<int32_t> order;    // order[k] = scene-file index of the k-th primitive in depth-first leaf order
+    int32_t root_ref = 0;
+    Box root_box;
+    int32_t max_depth = 0;         // interior-node levels on the longest root->leaf path
+};
+
+// World-space box of one shape at build time (transformed_shape.h:42-77, plane.cpp:11-46,
+// complex_sphere.cpp:21-27, complex_cube.cpp:25-31, complex_plane.cpp:24-75).
+Box shape_bounds(const RtShape& s, double shutter_time);
+
+// n_shapes == 0 yields an empty hierarchy (root_ref is a leaf of zero primitives; callers must check).
+HostBvh build_bvh(const RtSceneDesc& desc);
+
+}  // namespace rt

@@ -1,0 +1,926 @@
+// The render hot path on gfx950: one lane = one pixel, one wave = an 8x8 pixel tile, one launch = one part of a frame.
+//
+// Replaces, fused into a single kernel, the reference's per-pixel loop and everything under it:
+//   Code/main.cpp:281-322 (sample loop, average, tone map, 8-bit), Code/environment/camera.cpp:89-135 (rays),
+//   Code/utilities/tracer.h:147-308 (Whitted recursion -> bounded pending-ray stack), Code/utilities/shading.h
+//   (Blinn-Phong, soft shadows with coloured transmission), Code/acceleration/{bvh,aabb}.cpp (traversal),
+//   Code/shapes/*.cpp (sphere / quad / cube / displaced shapes), Code/utilities/Image.cpp + HDRImage.cpp (lookups).
+//
+// Arithmetic is FP64 throughout (the parity bar is 8-bit max|diff| <= 1 against an FP64 reference); compiled with
+// -ffp-contract=off so that sums and products round where the reference's do.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "render_kernel.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int kBlock = 256;            // 4 waves; each wave owns an 8x8 pixel tile, a block a 32x8 strip
+constexpr double kPi = 3.14159265358979323846;
+
+// ------------------------------------------------------------------------------------------ small vector algebra
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 mk(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ D3 ld3(const double* p) { return D3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a) { return D3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return D3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ D3 operator/(D3 a, double s) { return D3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ D3 cmul(D3 a, D3 b) { return D3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// vector3.h:92-102
+__device__ __forceinline__ D3 normalize(D3 a) {
+    double len = length(a);
+    if (len > 1e-6) return D3{a.x / len, a.y / len, a.z / len};
+    return D3{0.0, 0.0, 0.0};
+}
+// std::min / std::max semantics (a NaN second argument is ignored, a NaN first argument is returned)
+__device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ int imin(int a, int b) { return b < a ? b : a; }
+__device__ __forceinline__ int imax(int a, int b) { return a < b ? b : a; }
+// x86 cvttsd2si: out-of-range and NaN give INT_MIN (the device conversion would saturate / give 0).
+__device__ __forceinline__ int to_int(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+struct Ray {
+    D3 o, d;
+    double time;
+};
+
+// ------------------------------------------------------------------------------------------ random numbers
+// Counter-based stream per (seed, pixel, sample): splitmix64.  RT_RNG_D0 returns the constants of the oracle's "d0" mode.
+struct Rng {
+    unsigned long long s;
+    bool d0;
+    __device__ __forceinline__ unsigned long long next() {
+        unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    __device__ __forceinline__ double uniform() { return d0 ? 0.5 : (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    // random_utils.h:29-35 (rejection sampling of the unit ball)
+    __device__ D3 in_unit_sphere() {
+        if (d0) return mk(0, 0, 0);
+        for (int it = 0; it < 64; ++it) {  // acceptance 52 % per try; 64 tries leave 1e-21 of the mass
+            D3 p = mk(uniform() * 2 - 1, uniform() * 2 - 1, uniform() * 2 - 1);
+            if (dot(p, p) < 1.0) return p;
+        }
+        return mk(0, 0, 0);
+    }
+    // camera.cpp:13-24 (rejection sampling of the unit disk)
+    __device__ D3 in_unit_disk() {
+        if (d0) return mk(0, 0, 0);
+        for (int it = 0; it < 64; ++it) {
+            D3 p = mk(uniform() * 2.0 - 1.0, uniform() * 2.0 - 1.0, 0.0);
+            if (dot(p, p) < 1.0) return p;
+        }
+        return mk(0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ textures / environment
+struct Px {
+    int r, g, b;
+};
+__device__ __forceinline__ Px tex_get(const DTexture& t, int x, int y) {  // Image.cpp:191-200 (callers clamp)
+    const uint8_t* p = t.rgb + ((size_t)y * t.width + x) * 3;
+    return Px{p[0], p[1], p[2]};
+}
+// Image.cpp:7-65: clamp, interpolate, truncate each channel to 8 bits.
+__device__ Px tex_bilinear(const DTexture& t, double u, double v) {
+    u = smax(0.0, smin(1.0, u));
+    v = smax(0.0, smin(1.0, v));
+    double px = u * (t.width - 1), py = v * (t.height - 1);
+    int x0 = (int)floor(px), y0 = (int)floor(py);
+    int x1 = imin(x0 + 1, t.width - 1), y1 = imin(y0 + 1, t.height - 1);
+    double dx = px - x0, dy = py - y0;
+    Px c00 = tex_get(t, x0, y0), c10 = tex_get(t, x1, y0), c01 = tex_get(t, x0, y1), c11 = tex_get(t, x1, y1);
+    double rt = (1.0 - dx) * c00.r + dx * c10.r, gt = (1.0 - dx) * c00.g + dx * c10.g, bt = (1.0 - dx) * c00.b + dx * c10.b;
+    double rb = (1.0 - dx) * c01.r + dx * c11.r, gb = (1.0 - dx) * c01.g + dx * c11.g, bb = (1.0 - dx) * c01.b + dx * c11.b;
+    return Px{(int)(unsigned char)((1.0 - dy) * rt + dy * rb), (int)(unsigned char)((1.0 - dy) * gt + dy * gb),
+              (int)(unsigned char)((1.0 - dy) * bt + dy * bb)};
+}
+__device__ __forceinline__ double px_intensity(Px p) { return (p.r + p.g + p.b) / (3.0 * 255.0); }
+// sphere.cpp:143-152: clamped nearest texel intensity
+__device__ __forceinline__ double tex_intensity_at(const DTexture& t, int x, int y) {
+    x = imin(imax(x, 0), t.width - 1);
+    y = imin(imax(y, 0), t.height - 1);
+    return px_intensity(tex_get(t, x, y));
+}
+
+// HDRImage.cpp:112-182 with the angles of tracer.h:63-82
+__device__ D3 env_sample(const DScene& S, D3 dir) {
+    if (!S.env || S.env_w <= 0) return mk(0, 0, 0);
+    D3 d = normalize(dir);
+    double u = atan2(d.y, d.x), v = kPi - acos(d.z);
+    const int w = S.env_w, h = S.env_h;
+    double U = u / (2.0 * kPi), V = v / kPi;
+    double px = U * (w - 1), py = V * (h - 1);
+    px = fmod(px, (double)w);
+    if (px < 0) px += w;
+    {   // std::clamp(py, 0, h-1)
+        double hi = (double)(h - 1);
+        py = (py < 0.0) ? 0.0 : ((hi < py) ? hi : py);
+    }
+    int x0 = (int)floor(px), y0 = (int)floor(py);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    double dx = px - x0, dy = py - y0;
+    x1 = x1 % w;
+    if (x1 < 0) x1 += w;
+    y1 = imin(y1, h - 1);
+    x0 = imin(imax(x0, 0), w - 1);  // a NaN direction cannot index outside the map
+    y0 = imin(imax(y0, 0), h - 1);
+    auto at = [&](int x, int y) {
+        const float* p = S.env + ((size_t)y * w + x) * 3;
+        return mk((double)p[0], (double)p[1], (double)p[2]);
+    };
+    D3 c00 = at(x0, y0), c10 = at(x1, y0), c01 = at(x0, y1), c11 = at(x1, y1);
+    D3 bottom = c00 * (1.0 - dx) + c10 * dx, top = c01 * (1.0 - dx) + c11 * dx;
+    return bottom * (1.0 - dy) + top * dy;
+}
+
+// ------------------------------------------------------------------------------------------ object space
+struct ObjRay {
+    D3 o, d;
+};
+// sphere.cpp:47-53: origin moved back by velocity*time, then the point / direction transforms of matrix4x4.cpp:80-103.
+__device__ __forceinline__ ObjRay to_object(const DXform& X, const Ray& r) {
+    D3 o0 = r.o - ld3(X.vel) * r.time;
+    const double* m = X.inv;
+    double x = m[0] * o0.x + m[1] * o0.y + m[2] * o0.z + m[3];
+    double y = m[4] * o0.x + m[5] * o0.y + m[6] * o0.z + m[7];
+    double z = m[8] * o0.x + m[9] * o0.y + m[10] * o0.z + m[11];
+    double w = X.inv33;  // row 3 is (0,0,0,inv33) for the affine transforms the host accepts
+    ObjRay q;
+    q.o = (w != 0.0 && w != 1.0) ? mk(x / w, y / w, z / w) : mk(x, y, z);
+    q.d = mk(m[0] * r.d.x + m[1] * r.d.y + m[2] * r.d.z, m[4] * r.d.x + m[5] * r.d.y + m[6] * r.d.z,
+             m[8] * r.d.x + m[9] * r.d.y + m[10] * r.d.z);
+    return q;
+}
+// Normal transform: (inverse transpose) * n as a *point* (sphere.cpp:104, matrix4x4.cpp:80-93), then normalize.
+__device__ __forceinline__ D3 normal_to_world(const DXform& X, D3 n) {
+    const double* m = X.inv;
+    double x = m[0] * n.x + m[4] * n.y + m[8] * n.z;
+    double y = m[1] * n.x + m[5] * n.y + m[9] * n.z;
+    double z = m[2] * n.x + m[6] * n.y + m[10] * n.z;
+    double w = m[3] * n.x + m[7] * n.y + m[11] * n.z + X.inv33;
+    D3 v = (w != 0.0 && w != 1.0) ? mk(x / w, y / w, z / w) : mk(x, y, z);
+    return normalize(v);
+}
+
+__device__ __forceinline__ void sphere_uv(D3 p, double& u, double& v) {  // sphere.cpp:28-41
+    double theta = asin(p.y);
+    double phi = atan2(-p.z, p.x) + kPi;
+    u = phi / (2.0 * kPi);
+    v = (theta + kPi / 2.0) / kPi;
+}
+
+// cube.cpp:102-175 / complex_cube.cpp:49-118: face from the dominant coordinate, uv into the 4x3 cross atlas.
+__device__ void cube_face_uv(D3 p, bool clamp_raw, D3& n, double& u, double& v) {
+    double ax = fabs(p.x), ay = fabs(p.y), az = fabs(p.z);
+    int axis;
+    n = mk(0, 0, 0);
+    if (ax >= ay && ax >= az) { axis = 0; n.x = (p.x > 0) ? 1.0 : -1.0; }
+    else if (ay >= ax && ay >= az) { axis = 1; n.y = (p.y > 0) ? 1.0 : -1.0; }
+    else { axis = 2; n.z = (p.z > 0) ? 1.0 : -1.0; }
+    double ru, rv;
+    if (axis == 0) { ru = (p.y * (n.x > 0 ? -1 : 1) + 1.0) * 0.5; rv = (p.z + 1.0) * 0.5; }
+    else if (axis == 1) { ru = (p.x * (n.y > 0 ? 1 : -1) + 1.0) * 0.5; rv = (p.z + 1.0) * 0.5; }
+    else { ru = (p.x + 1.0) * 0.5; rv = (p.y + 1.0) * 0.5; }
+    if (clamp_raw) {
+        ru = smax(0.0, smin(1.0, ru));
+        rv = smax(0.0, smin(1.0, rv));
+    }
+    double uo, vo;
+    if (axis == 2) { uo = 1.0; vo = (n.z > 0) ? 2.0 : 0.0; }
+    else if (axis == 1) { uo = (n.y > 0) ? 1.0 : 3.0; vo = 1.0; }
+    else { uo = (n.x > 0) ? 2.0 : 0.0; vo = 1.0; }
+    u = (ru + uo) * 0.25;
+    v = (rv + vo) * (1.0 / 3.0);
+}
+
+// complex_cube.cpp:34-46 / complex_plane.cpp:78-92
+__device__ __forceinline__ double box_sdf(D3 p, D3 half) {
+    D3 d = mk(fabs(p.x), fabs(p.y), fabs(p.z)) - half;
+    double inside = smin(smax(d.x, smax(d.y, d.z)), 0.0);
+    double outside = length(mk(smax(d.x, 0.0), smax(d.y, 0.0), smax(d.z, 0.0)));
+    return inside + outside;
+}
+
+// Displaced-surface distance functions (complex_sphere.cpp:124-142, complex_cube.cpp:227-248, complex_plane.cpp:209-214).
+__device__ double sdf_complex_sphere(const DScene& S, const DMaterial& M, double D, D3 q, double* ou, double* ov) {
+    double ql = length(q);
+    D3 qu = q / ql;
+    double u, v;
+    sphere_uv(qu, u, v);
+    double disp = 0.0;
+    if (M.bump >= 0) disp = px_intensity(tex_bilinear(S.textures[M.bump], u, 1.0 - v)) * D;
+    if (ou) { *ou = u; *ov = v; }
+    return ql - (1.0 + disp);
+}
+__device__ double sdf_complex_cube(const DScene& S, const DMaterial& M, double D, D3 q, double* ou, double* ov) {
+    double u, v;
+    D3 n;
+    cube_face_uv(q, true, n, u, v);
+    double disp = 0.0;
+    if (M.bump >= 0) {
+        const DTexture& t = S.textures[M.bump];
+        int x = to_int(u * (t.width - 1)), y = to_int((1.0 - v) * (t.height - 1));
+        x = imax(0, imin(x, t.width - 1));
+        y = imax(0, imin(y, t.height - 1));
+        disp = px_intensity(tex_get(t, x, y)) * D;
+    }
+    if (ou) { *ou = u; *ov = v; }
+    return box_sdf(q, mk(1, 1, 1)) - disp;
+}
+__device__ double sdf_complex_plane(const DScene& S, const DMaterial& M, double D, D3 q, double* ou, double* ov) {
+    double u = (q.x + 1.0) * 0.5, v = (q.y + 1.0) * 0.5;
+    u = smax(0.0, smin(1.0, u));
+    v = smax(0.0, smin(1.0, v));
+    double disp = 0.0;
+    if (M.bump >= 0) disp = px_intensity(tex_bilinear(S.textures[M.bump], u, 1.0 - v)) * D;
+    if (ou) { *ou = u; *ov = v; }
+    return box_sdf(q, mk(1.0, 1.0, 0.001)) - disp;
+}
+__device__ __forceinline__ double sdf_complex(int type, const DScene& S, const DMaterial& M, double D, D3 q, double* ou, double* ov) {
+    if (type == RT_SHAPE_COMPLEX_SPHERE) return sdf_complex_sphere(S, M, D, q, ou, ov);
+    if (type == RT_SHAPE_COMPLEX_CUBE) return sdf_complex_cube(S, M, D, q, ou, ov);
+    return sdf_complex_plane(S, M, D, q, ou, ov);
+}
+
+// ------------------------------------------------------------------------------------------ primitive tests
+// Candidate = the closest accepted hit so far.  tri/bu/bv carry the quad's triangle and barycentrics.
+struct Cand {
+    double t;
+    int prim;   // -1 none
+    int tri;
+    double bu, bv;
+};
+
+// plane.cpp:77-134 (Moeller-Trumbore with the reference's un-normalised parallel test and strict t range)
+__device__ __forceinline__ bool tri_test(D3 o, D3 d, double tmin, double tmax, double eps, D3 v0, D3 e1, D3 e2, double& ot,
+                                         double& ou, double& ov) {
+    D3 h = cross(d, e2);
+    double a = dot(e1, h);
+    if (a > -eps && a < eps) return false;
+    double f = 1.0 / a;
+    D3 s = o - v0;
+    double u = f * dot(s, h);
+    if (u < 0.0 || u > 1.0) return false;
+    D3 q = cross(s, e1);
+    double v = f * dot(d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    ot = f * dot(e2, q);
+    if (ot > tmin && ot < tmax) { ou = u; ov = v; return true; }
+    return false;
+}
+
+// Slab entry/exit for the displaced cube / plane bounds (complex_cube.cpp:130-160, complex_plane.cpp:123-158).
+__device__ __forceinline__ bool slab_range(D3 oo, D3 od, D3 b, double& tn, double& tf) {
+    tn = -INFINITY;
+    tf = INFINITY;
+    const double o[3] = {oo.x, oo.y, oo.z}, d[3] = {od.x, od.y, od.z}, bv[3] = {b.x, b.y, b.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (d[i] == 0.0) {
+            if (o[i] < -bv[i] || o[i] > bv[i]) return false;
+        } else {
+            double t0 = (-bv[i] - o[i]) / d[i], t1 = (bv[i] - o[i]) / d[i];
+            if (d[i] < 0.0) { double s = t0; t0 = t1; t1 = s; }
+            if (t0 > tn) tn = t0;
+            if (t1 < tf) tf = t1;
+        }
+    }
+    return !(tn > tf || tf < 0.0);
+}
+
+// Ray-marched displaced shapes (complex_sphere.cpp:30-168, complex_cube.cpp:121-278, complex_plane.cpp:112-233).
+__device__ __noinline__ bool march_complex(const DScene& S, const DParams& P, const DPrim& pr, const Ray& r, double tmin, double tmax,
+                                           double& t_out) {
+    const DXform& X = S.xforms[pr.data];
+    const DMaterial& M = S.materials[pr.material];
+    const double D = X.disp;
+    ObjRay q = to_object(X, r);
+    double t, tl, step_scale = 1.0, step_mul;
+    if (pr.type == RT_SHAPE_COMPLEX_SPHERE) {
+        double max_r = 1.0 + D;
+        double a = dot(q.d, q.d), b = 2.0 * dot(q.o, q.d), c = dot(q.o, q.o) - max_r * max_r;
+        double disc = b * b - 4 * a * c;
+        if (disc < 0) return false;
+        double te = (-b - sqrt(disc)) / (2.0 * a), tx = (-b + sqrt(disc)) / (2.0 * a);
+        if (tx < tmin || te > tmax) return false;
+        t = smax(te, tmin);
+        tl = smin(tx, tmax);
+        step_mul = 0.5;
+    } else {
+        double tn, tf;
+        D3 bound = (pr.type == RT_SHAPE_COMPLEX_CUBE) ? mk(1.0 + D, 1.0 + D, 1.0 + D) : mk(1.0, 1.0, D + 0.01);
+        if (!slab_range(q.o, q.d, bound, tn, tf)) return false;
+        t = smax(tn, tmin);
+        tl = smin(tf, tmax);
+        if (pr.type == RT_SHAPE_COMPLEX_CUBE) {
+            step_mul = 0.6;
+        } else {
+            step_scale = length(q.d);  // complex_plane.cpp:121,229: only the plane converts to world units
+            step_mul = P.step_multiplier;
+        }
+    }
+    const double EPS = P.eps_march;
+    for (int i = 0; i < P.march_steps; ++i) {
+        if (t > tl) break;
+        D3 p = q.o + q.d * t;
+        double ds = sdf_complex(pr.type, S, M, D, p, nullptr, nullptr);
+        if (ds < EPS) { t_out = t; return true; }
+        if (pr.type == RT_SHAPE_COMPLEX_PLANE) t += smax((ds / step_scale) * step_mul, EPS);
+        else t += smax(ds * step_mul, EPS);
+    }
+    return false;
+}
+
+struct Counters {
+    unsigned int rays, nodes, prims;
+};
+
+// Tie rule.  The reference visits primitives in a fixed order and replaces the current hit when a later test
+// succeeds with t_max = current t: spheres/cubes/displaced shapes accept t == t_max (sphere.cpp:83, cube.cpp:85),
+// triangles do not (plane.cpp:126).  Among equal-t hits the reference therefore keeps the LAST inclusive
+// primitive in visit order, or the FIRST primitive if all are triangles.  `order` is that visit order, so the
+// result does not depend on the order this kernel happens to test primitives in.
+__device__ __forceinline__ bool tie_new_wins(bool new_incl, int new_order, bool cur_incl, int cur_order) {
+    if (new_incl != cur_incl) return new_incl;
+    return new_incl ? (new_order > cur_order) : (new_order < cur_order);
+}
+
+// One primitive against the ray; updates `best` when it is the new closest hit.
+__device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, const Ray& r, int prim, int order, double tmin,
+                                          Cand& best, int& best_order, bool& best_incl, Counters& C) {
+    const DPrim pr = S.prims[prim];
+    if (P.count_tests) C.prims++;
+    double t = 0.0, bu = 0.0, bv = 0.0;
+    int tri = 0;
+    bool hit = false, incl = true;
+    const double tmax = best.t;
+    if (pr.type == RT_SHAPE_SPHERE) {  // sphere.cpp:44-90
+        const DXform& X = S.xforms[pr.data];
+        ObjRay q = to_object(X, r);
+        double a = dot(q.d, q.d), b = 2.0 * dot(q.o, q.d), c = dot(q.o, q.o) - 1.0;
+        double disc = b * b - 4 * a * c;
+        if (!(disc < 0)) {
+            double sq = sqrt(disc);
+            double root = (-b - sq) / (2.0 * a);
+            hit = true;
+            if (root < tmin || root > tmax) {
+                root = (-b + sq) / (2.0 * a);
+                if (root < tmin || root > tmax) hit = false;
+            }
+            t = root;
+        }
+    } else if (pr.type == RT_SHAPE_PLANE) {  // plane.cpp:137-177
+        const DQuad& Q = S.quads[pr.data];
+        D3 o0 = r.o - ld3(Q.vel) * r.time;
+        double t1, u1, v1, t2, u2, v2;
+        bool h1 = tri_test(o0, r.d, tmin, tmax, P.eps_triangle, ld3(Q.v0), ld3(Q.e1), ld3(Q.e2), t1, u1, v1);
+        bool h2 = tri_test(o0, r.d, tmin, tmax, P.eps_triangle, ld3(Q.w0), ld3(Q.f1), ld3(Q.f2), t2, u2, v2);
+        incl = false;
+        if (h1 || h2) {
+            hit = true;
+            bool first = (h1 && h2) ? (t1 < t2) : h1;
+            t = first ? t1 : t2;
+            tri = first ? 0 : 1;
+            bu = first ? u1 : u2;
+            bv = first ? v1 : v2;
+        }
+    } else if (pr.type == RT_SHAPE_CUBE) {  // cube.cpp:25-89
+        const DXform& X = S.xforms[pr.data];
+        ObjRay q = to_object(X, r);
+        double tn = -INFINITY, tf = INFINITY;
+        const double o[3] = {q.o.x, q.o.y, q.o.z}, d[3] = {q.d.x, q.d.y, q.d.z};
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (!ok) break;
+            double t0, t1;
+            if (d[i] == 0.0) {
+                if (o[i] < -1.0 || o[i] > 1.0) { ok = false; break; }
+                t0 = -INFINITY;
+                t1 = INFINITY;
+            } else {
+                double id = 1.0 / d[i];
+                t0 = (-1.0 - o[i]) * id;
+                t1 = (1.0 - o[i]) * id;
+                if (id < 0.0) { double s = t0; t0 = t1; t1 = s; }
+            }
+            if (t0 > tn) tn = t0;
+            if (t1 < tf) tf = t1;
+            if (tn > tf) ok = false;
+            else if (tf < 0.0) ok = false;
+        }
+        if (ok) {
+            double th = tn;
+            hit = true;
+            if (th < tmin || th > tmax) {
+                th = tf;
+                if (th < tmin || th > tmax) hit = false;
+            }
+            t = th;
+        }
+    } else {
+        hit = march_complex(S, P, pr, r, tmin, tmax, t);
+    }
+    if (!hit) return;
+    bool take;
+    if (best.prim < 0) take = true;               // the test itself applied the range rule against the initial t_max
+    else if (t < best.t) take = true;
+    else if (t == best.t) take = tie_new_wins(incl, order, best_incl, best_order);
+    else take = false;
+    if (take) {
+        best.t = t;
+        best.prim = prim;
+        best.tri = tri;
+        best.bu = bu;
+        best.bv = bv;
+        best_order = order;
+        best_incl = incl;
+    }
+}
+
+// aabb.cpp:4-38, with 1/d hoisted out (same value).  Returns the entry distance in `entry`.
+__device__ __forceinline__ bool box_test(const double* lo, const double* hi, const double* o, const double* inv, double tmin,
+                                         double tmax, double& entry) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double t0 = (lo[a] - o[a]) * inv[a];
+        double t1 = (hi[a] - o[a]) * inv[a];
+        if (inv[a] < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    entry = tmin;
+    return true;
+}
+
+// Closest hit == `world.intersect(r, tmin, tmax, rec)` (hittable_list.cpp:8-33 over bvh.cpp:101-114).
+// Traversal is front-to-back with a per-lane stack of deferred children in LDS; the hit found equals the
+// reference's left-then-right recursion because closest-hit selection is order independent (ties: tie_new_wins).
+__device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, double tmin, double tmax, Cand& best, Counters& C,
+                            int (*stack)[kBlock]) {
+    C.rays++;
+    best.t = tmax;
+    best.prim = -1;
+    best.tri = 0;
+    best.bu = best.bv = 0.0;
+    int best_order = 0;
+    bool best_incl = false;
+    if (S.n_prims <= 0) return false;
+    if (!P.use_bvh) {  // --no-bvh: the list in scene-file order
+        for (int i = 0; i < S.n_prims; ++i) test_prim(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+        return best.prim >= 0;
+    }
+    const double o[3] = {r.o.x, r.o.y, r.o.z};
+    const double inv[3] = {1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
+    double e;
+    if (P.count_tests) C.nodes++;
+    if (!box_test(S.root_lo, S.root_hi, o, inv, tmin, tmax, e)) return false;
+    const int tid = threadIdx.x;
+    int sp = 0;
+    int cur = S.root_ref;
+    while (true) {
+        if (cur >= 0) {
+            const DNode* n = &S.nodes[cur];
+            if (P.count_tests) C.nodes += 2;
+            double e0, e1;
+            bool h0 = box_test(n->lo[0], n->hi[0], o, inv, tmin, best.t, e0);
+            bool h1 = box_test(n->lo[1], n->hi[1], o, inv, tmin, best.t, e1);
+            int c0 = n->child[0], c1 = n->child[1];
+            if (h0 && h1) {
+                bool left_first = !(e1 < e0);
+                stack[sp++][tid] = left_first ? c1 : c0;
+                cur = left_first ? c0 : c1;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            int code = ~cur;
+            int first = code >> 1;
+            test_prim(S, P, r, first, first, tmin, best, best_order, best_incl, C);
+            if (code & 1) test_prim(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+        }
+        if (sp == 0) break;
+        cur = stack[--sp][tid];
+    }
+    return best.prim >= 0;
+}
+
+// ------------------------------------------------------------------------------------------ hit record
+struct Hit {
+    double t;
+    D3 p, n;
+    double u, v;
+    int material;
+    bool front;
+};
+__device__ __forceinline__ void set_face_normal(Hit& h, const Ray& r, D3 outward) {  // hittable.h:35-42
+    h.front = dot(r.d, outward) < 0.0;
+    h.n = h.front ? outward : -outward;
+}
+
+// sphere.cpp:116-167 == cube.cpp:178-229
+__device__ D3 bump_nearest(const DTexture& T, D3 N, double u, double v) {
+    D3 Y = mk(0, 1, 0), Tn;
+    if (fabs(dot(N, Y)) > 0.999) Tn = mk(1, 0, 0);
+    else Tn = normalize(cross(Y, N));
+    D3 B = normalize(cross(N, Tn));
+    int w = T.width, h = T.height;
+    int x = to_int(u * (w - 1)), y = to_int((1.0 - v) * (h - 1));
+    double hc = tex_intensity_at(T, x, y), hu = tex_intensity_at(T, x + 1, y), hv = tex_intensity_at(T, x, y + 1);
+    double bu = (hu - hc) * w, bv = (hv - hc) * h;
+    return normalize(N + (Tn * bu + B * bv) * 0.0075);
+}
+
+// Everything the shapes' intersect() write into the HitRecord, recomputed for the winning candidate only.
+__device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const Cand& c, Hit& h) {
+    const DPrim pr = S.prims[c.prim];
+    const DMaterial& M = S.materials[pr.material];
+    h.t = c.t;
+    h.p = r.o + (c.t * r.d);  // ray.h:30-32
+    h.material = pr.material;
+    h.u = 0.0;
+    h.v = 0.0;
+    const bool need_uv = (M.texture >= 0) || (M.bump >= 0);
+    if (pr.type == RT_SHAPE_SPHERE) {  // sphere.cpp:92-171
+        const DXform& X = S.xforms[pr.data];
+        ObjRay q = to_object(X, r);
+        D3 on = (q.o + (c.t * q.d)) - mk(0, 0, 0);
+        D3 outward = normal_to_world(X, on);
+        if (need_uv) {
+            sphere_uv(normalize(on), h.u, h.v);
+            if (M.bump >= 0) outward = bump_nearest(S.textures[M.bump], outward, h.u, h.v);
+        }
+        set_face_normal(h, r, outward);
+    } else if (pr.type == RT_SHAPE_PLANE) {  // plane.cpp:179-243
+        const DQuad& Q = S.quads[pr.data];
+        D3 n = ld3(Q.n), outward = n;
+        if (c.tri == 0) { h.u = c.bu; h.v = c.bv; }
+        else { h.u = 1.0 - c.bv; h.v = c.bu + c.bv; }
+        if (M.bump >= 0) {
+            const DTexture& T = S.textures[M.bump];
+            D3 Tn = normalize(ld3(Q.e1)), B = normalize(ld3(Q.e2));
+            int w = T.width, hh = T.height;
+            double sx = 1.0 / w, sy = 1.0 / hh;
+            double hc = px_intensity(tex_bilinear(T, h.u, h.v));
+            double hu = px_intensity(tex_bilinear(T, h.u + sx, h.v));
+            double hv = px_intensity(tex_bilinear(T, h.u, h.v + sy));
+            double bu = (hu - hc) * w, bv = (hv - hc) * hh;
+            bu = smax(-100.0, smin(100.0, bu));
+            bv = smax(-100.0, smin(100.0, bv));
+            outward = normalize(n + (Tn * bu + B * bv) * 0.0075);
+        }
+        set_face_normal(h, r, outward);
+    } else if (pr.type == RT_SHAPE_CUBE) {  // cube.cpp:91-231
+        const DXform& X = S.xforms[pr.data];
+        ObjRay q = to_object(X, r);
+        D3 p = q.o + q.d * c.t, on;
+        double u, v;
+        cube_face_uv(p, false, on, u, v);
+        D3 outward = normal_to_world(X, on);
+        h.u = u;
+        h.v = v;
+        if (M.bump >= 0) outward = bump_nearest(S.textures[M.bump], outward, u, v);
+        set_face_normal(h, r, outward);
+    } else {  // complex_*.cpp: uv at the marched point, central-difference normal (step 0.005)
+        const DXform& X = S.xforms[pr.data];
+        ObjRay q = to_object(X, r);
+        D3 p = q.o + q.d * c.t;
+        const double D = X.disp;
+        (void)sdf_complex(pr.type, S, M, D, p, &h.u, &h.v);
+        const double e = 0.005;
+        double gx = sdf_complex(pr.type, S, M, D, p + mk(e, 0, 0), nullptr, nullptr) - sdf_complex(pr.type, S, M, D, p - mk(e, 0, 0), nullptr, nullptr);
+        double gy = sdf_complex(pr.type, S, M, D, p + mk(0, e, 0), nullptr, nullptr) - sdf_complex(pr.type, S, M, D, p - mk(0, e, 0), nullptr, nullptr);
+        double gz = sdf_complex(pr.type, S, M, D, p + mk(0, 0, e), nullptr, nullptr) - sdf_complex(pr.type, S, M, D, p - mk(0, 0, e), nullptr, nullptr);
+        D3 ln = normalize(mk(gx, gy, gz));
+        set_face_normal(h, r, normal_to_world(X, ln));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shading (shading.h)
+// shading.h:42-75, the recursion through transparent occluders unrolled into a loop (each level multiplies the
+// running transmission by its own tint; the < 0.001 cut-off is applied to the level's own factor, as there).
+__device__ D3 shadow_transmission(const DScene& S, const DParams& P, Ray sr, double dist, Counters& C, int (*stack)[kBlock]) {
+    D3 total = mk(1.0, 1.0, 1.0);
+    for (int seg = 0; seg < kShadowMaxSegments; ++seg) {
+        Cand c;
+        if (!closest_hit(S, P, sr, 0.001, dist - 0.001, c, C, stack)) return total;
+        Hit h;
+        fill_hit(S, P, sr, c, h);
+        const DMaterial& M = S.materials[h.material];
+        if (!(M.transparency > 0.0)) return mk(0, 0, 0);
+        double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
+        double eta = n1 / n2;
+        double cos_i = -dot(sr.d, h.n);
+        double sin2 = eta * eta * (1.0 - cos_i * cos_i);
+        if (sin2 > 1.0) return mk(0, 0, 0);
+        double r0 = ((n1 - n2) / (n1 + n2));
+        r0 = r0 * r0;
+        double refl = r0 + (1.0 - r0) * pow((1.0 - cos_i), 5.0);  // shadow_schlick, shading.h:24-28
+        D3 local = cmul(mk(1.0, 1.0, 1.0), ld3(M.diffuse)) * (1.0 - refl);
+        if (length(local) < 0.001) return mk(0, 0, 0);
+        total = cmul(total, local);
+        sr.o = h.p + sr.d * 0.001;
+        dist = dist - h.t;
+    }
+    return total;
+}
+
+// shading.h:79-101
+__device__ D3 light_visibility(const DScene& S, const DParams& P, const DLight& L, D3 Pt, D3 N, double time, Rng& rng, Counters& C,
+                               int (*stack)[kBlock]) {
+    if (!P.shadows) return mk(1.0, 1.0, 1.0);
+    D3 acc = mk(0, 0, 0);
+    for (int i = 0; i < P.shadow_samples; ++i) {
+        D3 lp = ld3(L.pos);
+        if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
+        D3 d = lp - Pt;
+        double dist = length(d);
+        d = normalize(d);
+        Ray sr{Pt + N * P.eps_shadow, d, time};
+        acc = acc + shadow_transmission(S, P, sr, dist, C, stack);
+    }
+    return acc * (1.0 / P.shadow_samples);
+}
+
+// shading.h:104-175 (ambient + diffuse) and shading.h:181-217 (specular); visibility is evaluated separately for
+// each, as the reference does.
+__device__ void shade_local(const DScene& S, const DParams& P, const Hit& h, const Ray& view, Rng& rng, Counters& C,
+                            int (*stack)[kBlock], D3& ad, D3& spec) {
+    const DMaterial& M = S.materials[h.material];
+    D3 base;
+    if (M.texture >= 0) {
+        const DTexture& T = S.textures[M.texture];
+        int x = to_int(h.u * (T.width - 1)), y = to_int((1.0 - h.v) * (T.height - 1));
+        x = imin(imax(x, 0), T.width - 1);
+        y = imin(imax(y, 0), T.height - 1);
+        Px p = tex_get(T, x, y);
+        base = mk(p.r / 255.0, p.g / 255.0, p.b / 255.0);
+    } else {
+        base = ld3(M.diffuse);
+    }
+    D3 colour = cmul(cmul(ld3(M.ambient), ld3(P.ambient_light)), base);
+    const D3 Pt = h.p, N = normalize(h.n);
+    for (int li = 0; li < S.n_lights; ++li) {
+        const DLight& L = S.lights[li];
+        D3 vis = light_visibility(S, P, L, Pt, N, view.time, rng, C, stack);
+        if (vis.x > 0 || vis.y > 0 || vis.z > 0) {
+            D3 Lr = ld3(L.pos) - Pt;
+            double falloff = 1.0 / dot(Lr, Lr);
+            D3 Ld = normalize(Lr);
+            D3 I = ld3(L.intensity) * falloff * P.exposure;
+            double ldn = smax(0.0, dot(Ld, N));
+            D3 diff = cmul(base, I) * ldn;
+            diff = diff * (1.0 - M.transparency);
+            colour = colour + cmul(diff, vis);
+        }
+    }
+    ad = colour;
+    const D3 V = normalize(view.o - Pt);
+    D3 sp = mk(0, 0, 0);
+    for (int li = 0; li < S.n_lights; ++li) {
+        const DLight& L = S.lights[li];
+        D3 vis = light_visibility(S, P, L, Pt, N, view.time, rng, C, stack);
+        if (length(vis) > 0) {
+            D3 Lr = ld3(L.pos) - Pt;
+            double falloff = 1.0 / dot(Lr, Lr);
+            D3 Ld = normalize(Lr);
+            D3 Hv = normalize(Ld + V);
+            D3 I = ld3(L.intensity) * falloff * P.exposure;
+            double hdn = smax(0.0, dot(Hv, N));
+            D3 part = cmul(ld3(M.specular), I) * exp(M.shininess * log(hdn));  // fast_pow, shading.h:177
+            sp = sp + cmul(part, vis);
+        }
+    }
+    spec = sp;
+}
+
+// ------------------------------------------------------------------------------------------ integrator (tracer.h)
+__device__ __forceinline__ D3 reflect(D3 V, D3 N) { return V - 2 * dot(V, N) * N; }  // tracer.h:57-60
+
+struct Pending {   // one not-yet-traced ray of the Whitted tree: colour contribution = weight (x) ray_colour(ray, depth)
+    D3 o, d, w;
+    int depth;
+};
+
+// camera.cpp:89-135
+__device__ Ray generate_ray(const DCamera& c, float px, float py, double time, Rng& rng) {
+    double uc = (0.5 - px) * c.sensor_width, vc = (py - 0.5) * c.sensor_height;
+    D3 dir = normalize((c.focal_length * ld3(c.w)) + (uc * ld3(c.u)) + (vc * ld3(c.v)));
+    if (c.aperture_radius <= 0.0) return Ray{ld3(c.location), dir, time};
+    D3 focal_point = ld3(c.location) + dir * c.focal_distance;
+    D3 disk = rng.in_unit_disk() * c.aperture_radius;
+    D3 origin = ld3(c.location) + (ld3(c.u) * disk.x + ld3(c.v) * disk.y);
+    return Ray{origin, normalize(focal_point - origin), time};
+}
+
+// tracer.h:23-54
+__device__ D3 tonemap(D3 c, int mode) {
+    if (mode == RT_TONEMAP_REINHARD) return mk(c.x / (1.0 + c.x), c.y / (1.0 + c.y), c.z / (1.0 + c.z));
+    if (mode == RT_TONEMAP_ACES) {
+        auto f = [](double x) { return (x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14); };
+        return mk(f(c.x), f(c.y), f(c.z));
+    }
+    if (mode == RT_TONEMAP_FILMIC) {
+        auto f = [](double x) {
+            const double A = 0.15, B = 0.50, Cc = 0.10, D = 0.20, E = 0.02, F = 0.30;
+            return ((x * (A * x + Cc * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+        };
+        double ws = 1.0 / f(11.2);
+        return mk(f(c.x) * ws, f(c.y) * ws, f(c.z) * ws);
+    }
+    return c;
+}
+__device__ __forceinline__ unsigned char quantise(double v) {  // tracer.h:297-308 (a NaN channel becomes 255)
+    double c = smax(0.0, smin(1.0, v));
+    return (unsigned char)(255 * c);
+}
+
+// ray_colour(ray, depth) of tracer.h:147-295 as a loop over a per-lane stack of pending rays.  The colour of a hit is
+// linear in the colours of its child rays, so each child carries the product of the weights above it and every
+// visited hit adds weight (x) local term to the pixel.
+__device__ D3 trace(const DScene& S, const DParams& P, const Ray& primary, Rng& rng, Counters& C, int (*tstack)[kBlock]) {
+    Pending stack[kRayStackDepth];
+    int sp = 0;
+    D3 accum = mk(0, 0, 0);
+    stack[sp++] = Pending{primary.o, primary.d, mk(1.0, 1.0, 1.0), P.max_depth};
+    const double eps = P.eps_scene;
+    const double time = primary.time;
+    while (sp > 0) {
+        Pending cur = stack[--sp];
+        if (cur.depth <= 0) continue;  // tracer.h:149
+        Ray r{cur.o, cur.d, time};
+        Cand c;
+        if (!closest_hit(S, P, r, eps, 100000.0, c, C, tstack)) {
+            D3 bg = S.env_present ? env_sample(S, r.d) : ld3(P.background);  // tracer.h:282-293
+            accum = accum + cmul(cur.w, bg);
+            continue;
+        }
+        Hit h;
+        fill_hit(S, P, r, c, h);
+        if (P.normals) {  // tracer.h:157-161
+            accum = accum + cmul(cur.w, (h.n + mk(1, 1, 1)) * 0.5);
+            continue;
+        }
+        D3 ad, spec;
+        shade_local(S, P, h, r, rng, C, tstack, ad, spec);
+        const DMaterial& M = S.materials[h.material];
+        const bool transparent = M.transparency > 0;
+        bool has_refl = M.reflectivity > 0;
+        if (transparent && P.fresnel) has_refl = true;
+
+        double reflect_prob = M.reflectivity, transmit_prob = M.transparency;
+        bool do_refract = false, tir_mirror = false;
+        D3 refr_dir = mk(0, 0, 0), Vin = mk(0, 0, 0), Nh = mk(0, 0, 0);
+        if (transparent) {  // tracer.h:226-266 with compute_refraction tracer.h:100-143
+            Vin = normalize(r.d);
+            Nh = normalize(h.n);
+            double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
+            double eta = n1 / n2;
+            double cos_i = -dot(Vin, Nh);
+            double sin2 = eta * eta * (1.0 - cos_i * cos_i);
+            if (sin2 > 1.0) {
+                transmit_prob = 0.0;
+                reflect_prob = 1.0;
+                tir_mirror = !has_refl;
+            } else {
+                double cos_t = sqrt(1.0 - sin2);
+                refr_dir = (eta * Vin) + (eta * cos_i - cos_t) * Nh;
+                do_refract = true;
+                if (P.fresnel) {
+                    double r0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));  // schlick, tracer.h:88-97
+                    double x = 1.0 - cos_i;
+                    reflect_prob = r0 + (1.0 - r0) * (x * x * x * x * x);
+                    transmit_prob = 1.0 - reflect_prob;
+                }
+            }
+        }
+        // tracer.h:268-279
+        D3 local;
+        double refl_weight;
+        if (transparent) { local = spec; refl_weight = reflect_prob; }
+        else { local = ad * (1.0 - M.reflectivity) + spec; refl_weight = M.reflectivity; }
+        accum = accum + cmul(cur.w, local);
+
+        const int child_depth = cur.depth - 1;
+        if (child_depth <= 0) continue;  // children would return black without tracing (tracer.h:149)
+        if (has_refl) {  // tracer.h:176-219
+            int samples = P.glossy_samples;
+            if (cur.depth < P.max_bounces) samples = 1;
+            double rough = 1.0 / sqrt(M.shininess);
+            D3 V = normalize(r.d);
+            D3 perfect = normalize(reflect(V, h.n));
+            D3 wr = cur.w * refl_weight;
+            if (M.is_metal) wr = cmul(wr, ld3(M.diffuse));
+            D3 org = h.p + h.n * eps;
+            if (samples > 0) {
+                wr = wr * (1.0 / samples);
+                for (int i = 0; i < samples; ++i) {
+                    D3 off = rng.in_unit_sphere() * rough;
+                    D3 target = normalize(perfect + off);
+                    if (dot(target, h.n) > 0 && sp < kRayStackDepth) stack[sp++] = Pending{org, target, wr, child_depth};
+                }
+            } else if (sp < kRayStackDepth) {
+                stack[sp++] = Pending{org, perfect, wr, child_depth};
+            }
+        }
+        if (tir_mirror && sp < kRayStackDepth)  // tracer.h:258-264 (not tinted for metals)
+            stack[sp++] = Pending{h.p + Nh * eps, normalize(reflect(Vin, Nh)), cur.w * reflect_prob, child_depth};
+        if (do_refract && sp < kRayStackDepth)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
+            stack[sp++] = Pending{h.p, normalize(refr_dir), cmul(cur.w * transmit_prob, ld3(M.diffuse)), child_depth};
+    }
+    return accum;
+}
+
+// ------------------------------------------------------------------------------------------ the kernel
+__global__ void __launch_bounds__(kBlock) k_render(const DScene S, const DParams P, uint8_t* __restrict__ out,
+                                                   unsigned long long* __restrict__ counters) {
+    __shared__ int tstack[kTravStackDepth][kBlock];
+
+    // XCD-aware block order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+    // L2); remap so that every XCD works on one contiguous run of image tiles and re-uses the BVH nodes it pulled in.
+    const int nblk = gridDim.x;
+    const int q = nblk / 8, rem = nblk % 8;
+    const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+    const int blk = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
+
+    const int blocks_x = (P.width + 31) / 32;
+    const int bx = blk % blocks_x, by = blk / blocks_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = bx * 32 + wave * 8 + (lane & 7);
+    const int lr = by * 8 + (lane >> 3);   // row inside this part's compact slice
+    const bool active = (x < P.width) && (lr < P.part_rows);
+
+    Counters C{0u, 0u, 0u};
+    if (active) {
+        // compact row -> frame row: tile k of the slice is frame tile k*part_count + part_index
+        const int y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
+        D3 acc = mk(0, 0, 0);
+        for (int s = 0; s < P.spp; ++s) {  // main.cpp:288-306
+            Rng rng;
+            rng.d0 = (P.rng_mode == RT_RNG_D0);
+            rng.s = (P.seed * 0x9E3779B97F4A7C15ull) ^
+                    (((unsigned long long)y * P.width + x) * 0xD1B54A32D192ED03ull + (unsigned long long)s * 0x8CB92BA72F3D8DD7ull);
+            float ru = (float)rng.uniform(), rv = (float)rng.uniform();
+            float px = ((float)x + ru) / (float)P.width;
+            float py = ((float)y + rv) / (float)P.height;
+            double time = rng.uniform() * S.shutter_time;
+            Ray ray = generate_ray(S.cam, px, py, time, rng);
+            acc = acc + trace(S, P, ray, rng, C, tstack);
+        }
+        D3 avg = tonemap(acc * (1.0 / P.spp), P.tonemap);  // main.cpp:308-316
+        uint8_t* o = out + ((size_t)lr * P.width + x) * 3;
+        o[0] = quantise(avg.x);
+        o[1] = quantise(avg.y);
+        o[2] = quantise(avg.z);
+    }
+    if (counters) {  // one atomic per wave and counter
+        unsigned int rays = C.rays, nodes = C.nodes, prims = C.prims;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_down(rays, off);
+            nodes += __shfl_down(nodes, off);
+            prims += __shfl_down(prims, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)rays);
+            if (P.count_tests) {
+                atomicAdd(&counters[1], (unsigned long long)nodes);
+                atomicAdd(&counters[2], (unsigned long long)prims);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_render(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
+                         hipStream_t stream) {
+    const int blocks_x = (params.width + 31) / 32;
+    const int blocks_y = (params.part_rows + 7) / 8;
+    const int nblk = blocks_x * blocks_y;
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_render, dim3(nblk), dim3(kBlock), 0, stream, scene, params, d_rgb8, d_counters);
+    return hipGetLastError();
+}
+
+}  // namespace rt
