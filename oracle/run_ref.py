@@ -53,7 +53,7 @@ def run_reference(scene_text, config_text, flags=(), rng="d0", texture_dirs=(), 
         os.makedirs(os.path.join(root, "Textures"))
         for d in texture_dirs:
             for name in os.listdir(d):
-                src = os.path.join(d, name)
+                src = os.path.abspath(os.path.join(d, name))
                 if os.path.isfile(src):
                     os.symlink(src, os.path.join(root, "Textures", name))
         with open(os.path.join(root, "Code", "config.json"), "w") as f:

@@ -270,8 +270,10 @@ struct Cand {
 };
 
 // plane.cpp:77-134 (Moeller-Trumbore with the reference's un-normalised parallel test and strict t range)
-__device__ __forceinline__ bool tri_test(D3 o, D3 d, double tmin, double tmax, double eps, D3 v0, D3 e1, D3 e2, double& ot,
-                                         double& ou, double& ov) {
+// `closed_top` admits t == tmax: used once a hit exists, so that an equal-t triangle reaches the tie rule instead of
+// being decided by this kernel's own visiting order (see tie_new_wins).
+__device__ __forceinline__ bool tri_test(D3 o, D3 d, double tmin, double tmax, bool closed_top, double eps, D3 v0, D3 e1, D3 e2,
+                                         double& ot, double& ou, double& ov) {
     D3 h = cross(d, e2);
     double a = dot(e1, h);
     if (a > -eps && a < eps) return false;
@@ -283,7 +285,7 @@ __device__ __forceinline__ bool tri_test(D3 o, D3 d, double tmin, double tmax, d
     double v = f * dot(d, q);
     if (v < 0.0 || u + v > 1.0) return false;
     ot = f * dot(e2, q);
-    if (ot > tmin && ot < tmax) { ou = u; ov = v; return true; }
+    if (ot > tmin && (ot < tmax || (closed_top && ot == tmax))) { ou = u; ov = v; return true; }
     return false;
 }
 
@@ -391,8 +393,8 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
         const DQuad& Q = S.quads[pr.data];
         D3 o0 = r.o - ld3(Q.vel) * r.time;
         double t1, u1, v1, t2, u2, v2;
-        bool h1 = tri_test(o0, r.d, tmin, tmax, P.eps_triangle, ld3(Q.v0), ld3(Q.e1), ld3(Q.e2), t1, u1, v1);
-        bool h2 = tri_test(o0, r.d, tmin, tmax, P.eps_triangle, ld3(Q.w0), ld3(Q.f1), ld3(Q.f2), t2, u2, v2);
+        bool h1 = tri_test(o0, r.d, tmin, tmax, best.prim >= 0, P.eps_triangle, ld3(Q.v0), ld3(Q.e1), ld3(Q.e2), t1, u1, v1);
+        bool h2 = tri_test(o0, r.d, tmin, tmax, best.prim >= 0, P.eps_triangle, ld3(Q.w0), ld3(Q.f1), ld3(Q.f2), t2, u2, v2);
         incl = false;
         if (h1 || h2) {
             hit = true;

@@ -1,0 +1,66 @@
+"""Shared helpers of the parity tests: load a golden case (scene text, config, reference-style flags) into the
+objects of raytracer_amd, exactly the way the reference's main() would interpret them (Code/main.cpp:82-226)."""
+import json
+import os
+
+import numpy as np
+
+import raytracer_amd as rt
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLD, "manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+CASES = sorted(MANIFEST)
+
+
+def flags_to_kwargs(flags):
+    """Reference CLI flags -> (apply_flags kwargs, shutter_time override or None).  Unknown tokens are ignored, as
+    main.cpp:219-226 does."""
+    kw, shutter, i = {}, None, 0
+    while i < len(flags):
+        f = flags[i]
+        if f == "--aa":
+            kw["aa"] = int(flags[i + 1]); i += 1
+        elif f == "--exposure":
+            kw["exposure"] = float(flags[i + 1]); i += 1
+        elif f == "--shadows":
+            kw["shadows"] = 1
+        elif f == "--glossy":
+            kw["glossy"] = 1
+        elif f == "--fresnel":
+            kw["fresnel"] = 1
+        elif f == "--normals":
+            kw["normals"] = 1
+        elif f == "--no-bvh":
+            kw["no_bvh"] = 1
+        elif f == "--tonemap":
+            kw["tonemap"] = flags[i + 1]; i += 1
+        elif f == "--motion-blur":
+            shutter = float(flags[i + 1]); i += 1
+        i += 1
+    return kw, shutter
+
+
+def load_case(name, rng="d0", **extra):
+    """-> (SceneFile, RtRenderParams, golden image or None)"""
+    with open(os.path.join(GOLD, "configs", name + ".json")) as f:
+        cfg = rt.Config(text=f.read())
+    kw, shutter = flags_to_kwargs(MANIFEST[name]["flags"])
+    kw.update(extra)
+    with open(os.path.join(GOLD, "scenes", name + ".txt"), newline="") as f:
+        text = f.read()
+    scene = rt.SceneFile(text=text, texture_root=os.path.join(GOLD, "scenes"), config=cfg, shutter_time=shutter)
+    params = cfg.params(rng=rng, **kw)
+    img_path = os.path.join(GOLD, "images", name + ".npz")
+    golden = np.load(img_path)["image"] if os.path.exists(img_path) else None
+    return scene, params, golden
+
+
+def diff_stats(a, b):
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    return int(d.max()), int((d > 0).sum()), int((d > 1).sum())
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
