@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X render core (contract: see the task's driver).
+
+Metric (BASELINE.json): Mrays/s (primary + secondary) and ms/frame, 1080p Whitted, 1/2/4/8 GPUs.
+Workload: BASELINE config 2 — 10^6 seeded random ellipsoids (raytracer_amd.workloads.bvh_stress_scene), 1920x1080,
+1 spp, default flags, shipped config values; deterministic sampling (RT_RNG_D0) so that every step traces the same rays.
+
+A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernel (C-ABI
+rt_render_device on torch's current stream), the u8 slices are gathered to rank 0 over RCCL and de-interleaved there.
+The scene is already resident in HBM when the timed region starts.  value = rays of all ranks / max-over-ranks time.
+Scaling is "strong": the frame (total work) is fixed as N grows.
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (BVH-node + primitive bytes per second of the render kernel,
+HIP events around each launch, against the 8 TB/s HBM peak) and "cpu_baseline" (the CPU oracle, OpenMP, on this
+host's cores; N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import raytracer_amd as rt  # noqa: E402
+from raytracer_amd import workloads  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NODE_BYTES_PER_BOX = 64   # one 128-byte DNode carries two child boxes (device_types.h)
+SPHERE_BYTES = 16 + 144   # DPrim header + DXform (device_types.h)
+RAY_STATE_BYTES = 16      # amortised framebuffer + ray state traffic per ray
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spheres", type=int, default=1_000_000, help="C2 primitive count (default = the named config)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the same frame")
+    ap.add_argument("--cpu-passes", type=int, default=6, help="CPU baseline: frames rendered (sized for ~10 s of CPU work)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_desc, params, row_step, passes):
+    """Oracle (port of the reference algorithm, oracle/rt_oracle.cpp) timed on this host: pixel loop only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    h = scene_desc.height
+    secs, rays = 0.0, 0
+    for _ in range(max(1, passes)):
+        _, cnt = oracle_py.render(scene_desc, params, threads=threads, counters=True, rows=(0, h, row_step))
+        secs += oracle_py.last_render_seconds()
+        rays += cnt[0]
+    return {
+        "value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": oracle_py.last_threads(), "kind": "port",
+        "sample": "same 10^6-sphere 1080p frame, every %d-th row, %d passes (%d rays), pixel loop only (BVH build excluded), %.2f s on %d threads"
+                  % (row_step, passes, rays, secs, oracle_py.last_threads()),
+        "box_tests_per_ray": round(cnt[1] / cnt[0], 2), "prim_tests_per_ray": round(cnt[2] / cnt[0], 2),
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    rt.init(local_rank)
+
+    cfg = workloads.default_config()
+    scene_desc = workloads.bvh_stress_scene(args.spheres, args.width, args.height)
+    params = cfg.params(rng="d0")
+    params.tile_rows, params.part_index, params.part_count = args.tile_rows, rank, world
+    scene = rt.Scene(scene_desc)  # BVH build + upload: outside the timed region (scene resident in HBM)
+    W, H = args.width, args.height
+    my_rows = rt.part_rows(H, args.tile_rows, rank, world)
+    max_rows = max(rt.part_rows(H, args.tile_rows, k, world) for k in range(world))
+    slice_t = torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    gathered = [torch.empty_like(slice_t) for _ in range(world)] if (world > 1 and rank == 0) else None
+    frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    # frame row -> (part, local row) gather index for the de-interleave on rank 0
+    if rank == 0 and world > 1:
+        src = np.empty(H, dtype=np.int64)
+        n_tiles = (H + args.tile_rows - 1) // args.tile_rows
+        for k in range(world):
+            lr = 0
+            for t in range(k, n_tiles, world):
+                y0 = t * args.tile_rows
+                rows = min(args.tile_rows, H - y0)
+                src[y0:y0 + rows] = k * max_rows + lr + np.arange(rows)
+                lr += rows
+        src_idx = torch.from_numpy(src).to(dev)
+
+    # a non-default torch stream: kernel, events, RCCL gather and de-interleave are all ordered on it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None, collect=False):
+        if i is not None:
+            ev[i][0].record(stream)
+        scene.render_device(params, slice_t.data_ptr(), counters.data_ptr(), collect_counters=collect, stream=stream.cuda_stream)
+        if i is not None:
+            ev[i][1].record(stream)
+        if world > 1:
+            dist.gather(slice_t, gathered, dst=0)
+            if rank == 0:
+                torch.index_select(torch.cat(gathered, 0), 0, src_idx, out=frame)
+        # world == 1: slice_t already is the frame
+
+    # one untimed counting pass: rays, box tests, primitive tests per frame of this rank
+    counters.zero_()
+    step(collect=True)
+    torch.cuda.synchronize(dev)
+    c = counters.cpu().numpy().astype(np.int64)
+    if world > 1:
+        tot = torch.from_numpy(c).to(dev)
+        dist.all_reduce(tot)
+        c_all = tot.cpu().numpy()
+    else:
+        c_all = c
+    rays_frame, boxes_frame, prims_frame = int(c_all[0]), int(c_all[1]), int(c_all[2])
+    rays_rank, boxes_rank, prims_rank = int(c[0]), int(c[1]), int(c[2])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / max(1, args.steps)
+        value = rays_frame * args.steps / elapsed / 1e6
+        alg_bytes = boxes_rank * NODE_BYTES_PER_BOX + prims_rank * SPHERE_BYTES + rays_rank * RAY_STATE_BYTES
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                t = json.load(open(tp))
+                if t.get("spheres") == args.spheres and t.get("n_gpus", 1) == world:
+                    traffic = t.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+secondary) & ms/frame, 1080p Whitted, 1/2/4/8 GPUs", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: %d random ellipsoids (default_rng(12345)), %dx%d, Whitted 1 spp, default flags, BVH on"
+                                   % (args.spheres, W, H),
+                       "partition": "interleaved row tiles of %d rows over %d GPU(s), u8 slices gathered to rank 0 (RCCL)"
+                                    % (args.tile_rows, world),
+                       "rays_per_frame": rays_frame, "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
+                       "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)"},
+            "ms_per_frame": round(ms_per_step, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_render", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_ray": "64*box_tests + 160*sphere_tests + 16"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            p1 = params.copy()
+            p1.part_count, p1.part_index = 1, 0
+            out["cpu_baseline"] = cpu_baseline(scene_desc, p1, args.cpu_row_step, args.cpu_passes)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,8 @@ def lib():
         _lib.rt_oracle_render.argtypes = [vp, vp, vp, i32, vp]
         _lib.rt_oracle_render_float.restype = i32
         _lib.rt_oracle_render_float.argtypes = [vp, vp, vp, i32]
+        _lib.rt_oracle_last_render_seconds.restype = C.c_double
+        _lib.rt_oracle_last_threads.restype = i32
     return _lib
 
 
@@ -49,3 +51,11 @@ def render_float(scene_desc, params, threads=0):
     if rc != 0:
         raise RuntimeError("oracle render failed: %d" % rc)
     return img
+
+
+def last_render_seconds():
+    return lib().rt_oracle_last_render_seconds()
+
+
+def last_threads():
+    return lib().rt_oracle_last_threads()

@@ -1047,6 +1047,9 @@ std::unique_ptr<World> make_world(const RtSceneDesc& d, const RtRenderParams& p)
 
 }  // namespace
 
+static double g_last_render_seconds = 0.0;
+static int g_last_threads = 1;
+
 extern "C" {
 
 // Render rows [row_begin, row_end) with stride row_step of the frame (row_step > 1 renders a sample of rows for
@@ -1064,6 +1067,10 @@ int rt_oracle_render_rows(const RtSceneDesc* desc, const RtRenderParams* params,
     int nrows = (row_end - row_begin + row_step - 1) / row_step;
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
+#endif
+    double t_begin = 0.0;
+#ifdef _OPENMP
+    t_begin = omp_get_wtime();
 #endif
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : tot_rays, tot_boxes, tot_prims)
     for (int k = 0; k < nrows; ++k) {  // main.cpp:281
@@ -1094,9 +1101,18 @@ int rt_oracle_render_rows(const RtSceneDesc* desc, const RtRenderParams* params,
         tot_prims += local.prims;
         tl_counters = nullptr;
     }
+#ifdef _OPENMP
+    g_last_render_seconds = omp_get_wtime() - t_begin;
+    g_last_threads = omp_get_max_threads();
+#endif
     if (counters) { counters[0] = tot_rays; counters[1] = tot_boxes; counters[2] = tot_prims; }
     return 0;
 }
+
+// Wall time of the pixel loop of the last rt_oracle_render_rows call (scene construction and BVH build excluded —
+// the reference's own timer includes them, main.cpp:230,350) and the OpenMP thread count it ran with.
+double rt_oracle_last_render_seconds(void) { return g_last_render_seconds; }
+int rt_oracle_last_threads(void) { return g_last_threads; }
 
 int rt_oracle_render(const RtSceneDesc* desc, const RtRenderParams* params, uint8_t* rgb8_out, int threads, uint64_t* counters) {
     if (!desc) return -1;

@@ -1,0 +1,42 @@
+"""Synthetic workloads of BASELINE.json / SURVEY 8(d), built in memory (nothing is read from the reference tree)."""
+import os
+
+import numpy as np
+
+import raytracer_amd as rt
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_CONFIG_PATH = os.path.join(_HERE, "default_config.json")  # same keys and values as the shipped Code/config.json
+
+
+def default_config():
+    return rt.Config(path=DEFAULT_CONFIG_PATH)
+
+
+def bvh_stress_scene(n_spheres=1_000_000, width=1920, height=1080, seed=12345, shutter_time=0.5):
+    """Config C2: camera and light of ASCII/BVH_tests/scene_3.txt:8-25 with `resolution` set to width x height and
+    n_spheres SPHERE blocks with the default material: translation ~ U([-0.8,1.8] x [-0.8,1.6] x [-1.2,1.05]) (the
+    extent of scene_100.txt), per-axis scale ~ U(0.5 r, 1.5 r) with r = 0.35 / cbrt(N), rotation about z ~ U(-pi, pi),
+    numpy default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    n = int(n_spheres)
+    trs = np.zeros((n, 9), dtype=np.float64)
+    trs[:, 0] = rng.uniform(-0.8, 1.8, n)
+    trs[:, 1] = rng.uniform(-0.8, 1.6, n)
+    trs[:, 2] = rng.uniform(-1.2, 1.05, n)
+    trs[:, 5] = rng.uniform(-np.pi, np.pi, n)
+    r = 0.35 / np.cbrt(n)
+    trs[:, 6:9] = rng.uniform(0.5 * r, 1.5 * r, (n, 3))
+    shapes = rt.shapes_from_trs(trs, rt.RT_SHAPE_SPHERE, 0)
+    cam = rt.RtCamera()
+    cam.location[:] = [2.5, -2.5, 1.5]
+    cam.gaze_direction[:] = [-0.506798, 0.760196, -0.406519]
+    cam.up_vector[:] = [-0.225496, 0.338244, 0.913642]
+    cam.focal_length, cam.sensor_width, cam.sensor_height = 50.0, 36.0, 24.0
+    cam.resolution_x, cam.resolution_y = width, height
+    cam.f_stop, cam.focal_distance = 99999.0, 10.0
+    light = rt.RtLight()
+    light.position[:] = [0.233330, 0.717368, 1.959181]
+    light.intensity[:] = [10.0, 10.0, 10.0]
+    light.radius = 0.0
+    return rt.SceneBuilder(cam, [light], shapes, [rt.default_material()], shutter_time=shutter_time)
