@@ -133,6 +133,10 @@ typedef struct RtSceneDesc {
  * ---------------------------------------------------------------------------------------------- */
 enum { RT_TONEMAP_NONE = 0, RT_TONEMAP_REINHARD = 1, RT_TONEMAP_ACES = 2, RT_TONEMAP_FILMIC = 3 }; /* main.cpp:68 */
 enum {
+    RT_SCHEDULE_WAVEFRONT = 0,  /* ray queues in HBM: persistent traversal kernel + shading kernel per level (default) */
+    RT_SCHEDULE_MEGAKERNEL = 1  /* one launch, one lane per pixel with a bounded pending-ray stack                   */
+};
+enum {
     RT_RNG_D0 = 0,      /* deterministic: every uniform 0.5, ball/disk samples 0 (oracle mode "d0") */
     RT_RNG_SEEDED = 1   /* counter-based generator keyed by (seed, pixel, sample, draw index)     */
 };
@@ -165,7 +169,7 @@ typedef struct RtRenderParams {
     int32_t tile_rows;
     int32_t part_index;
     int32_t part_count;
-    int32_t reserved;
+    int32_t schedule;            /* RT_SCHEDULE_*: how the device evaluates the ray tree (same pixels either way) */
 } RtRenderParams;
 
 typedef struct RtStats {

@@ -13,12 +13,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "librt_mi355x.so")  # override: A/B builds of the same ABI
 
 RT_SHAPE_SPHERE, RT_SHAPE_PLANE, RT_SHAPE_CUBE = 0, 1, 2
 RT_SHAPE_COMPLEX_SPHERE, RT_SHAPE_COMPLEX_CUBE, RT_SHAPE_COMPLEX_PLANE = 3, 4, 5
 RT_TONEMAP_NONE, RT_TONEMAP_REINHARD, RT_TONEMAP_ACES, RT_TONEMAP_FILMIC = 0, 1, 2, 3
 RT_RNG_D0, RT_RNG_SEEDED = 0, 1
+RT_SCHEDULE_WAVEFRONT, RT_SCHEDULE_MEGAKERNEL = 0, 1
 RT_ERR_INVALID, RT_ERR_IO, RT_ERR_DEVICE, RT_ERR_NOT_INIT, RT_ERR_LIMIT = -1, -2, -3, -4, -5
 TONEMAP_BY_NAME = {"none": 0, "reinhard": 1, "aces": 2, "filmic": 3}  # main.cpp:198-216
 
@@ -78,7 +79,7 @@ class RtRenderParams(C.Structure):
                 ("eps_scene", C.c_double), ("eps_triangle", C.c_double), ("eps_march", C.c_double),
                 ("eps_shadow", C.c_double), ("step_multiplier", C.c_double), ("background", C.c_double * 3),
                 ("ambient_light", C.c_double * 3), ("seed", C.c_uint64), ("tile_rows", C.c_int32),
-                ("part_index", C.c_int32), ("part_count", C.c_int32), ("reserved", C.c_int32)]
+                ("part_index", C.c_int32), ("part_count", C.c_int32), ("schedule", C.c_int32)]
 
     def copy(self):
         o = RtRenderParams()

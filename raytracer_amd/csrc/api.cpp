@@ -3,6 +3,7 @@
 // rt_render* call runs the HIP kernel of render_kernel.hip or fails with RT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,7 @@ struct rt_scene_s {
     DScene d{};                       // device view (pointers are device pointers)
     std::vector<void*> allocations;   // everything to hipFree
     uint8_t* d_frame = nullptr;       // scratch framebuffer for rt_render
+    WavefrontWorkspace wf;            // queues / accumulators of the wavefront schedule
     size_t d_frame_bytes = 0;
     bool on_device = false;
 };
@@ -317,6 +319,7 @@ void rt_scene_destroy(rt_scene_t scene) {
         (void)hipSetDevice(g_dev.device);
         for (void* p : scene->allocations) (void)hipFree(p);
         if (scene->d_frame) (void)hipFree(scene->d_frame);
+        wavefront_workspace_free(scene->wf);
     }
     delete scene;
 }
@@ -362,8 +365,9 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     if (p->rng_mode != RT_RNG_D0 && p->rng_mode != RT_RNG_SEEDED) return fail(RT_ERR_INVALID, "unknown rng_mode");
     if (p->shadows && p->shadow_samples <= 0) return fail(RT_ERR_INVALID, "shadow_samples must be >= 1 when shadows are on");
     if (p->glossy_samples < 0) return fail(RT_ERR_INVALID, "glossy_samples must be >= 0");
-    // Pending-ray stack bound: the first hit may queue glossy_samples + 1 rays, every deeper level at most one more.
-    if (std::max(p->max_depth, 0) + p->glossy_samples + 2 > kRayStackDepth)
+    if (p->schedule != RT_SCHEDULE_WAVEFRONT && p->schedule != RT_SCHEDULE_MEGAKERNEL) return fail(RT_ERR_INVALID, "unknown schedule");
+    // Megakernel pending-ray stack bound: the first hit may queue glossy_samples + 1 rays, every deeper level at most one more.
+    if (p->schedule == RT_SCHEDULE_MEGAKERNEL && std::max(p->max_depth, 0) + p->glossy_samples + 2 > kRayStackDepth)
         return fail(RT_ERR_LIMIT, "max_depth + glossy_samples exceeds the pending-ray stack (" + std::to_string(kRayStackDepth) + ")");
     int parts = p->part_count <= 1 ? 1 : p->part_count;
     int tile = p->tile_rows > 0 ? p->tile_rows : 8;
@@ -394,7 +398,11 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
     if (dp.part_rows == 0) return RT_OK;
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
-    hipError_t e = launch_render(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
+    hipError_t e;
+    if (params->schedule == RT_SCHEDULE_MEGAKERNEL)
+        e = launch_render_mega(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
+    else
+        e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st, scene->wf);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }
@@ -410,6 +418,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
     size_t bytes = static_cast<size_t>(rows) * scene->width * 3;
     if (scene->d_frame_bytes < bytes) {
         if (scene->d_frame) (void)hipFree(scene->d_frame);
+        wavefront_workspace_free(scene->wf);
         scene->d_frame = nullptr;
         scene->d_frame_bytes = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame), bytes ? bytes : 1));

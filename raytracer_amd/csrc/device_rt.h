@@ -1,23 +1,17 @@
-// The render hot path on gfx950: one lane = one pixel, one wave = an 8x8 pixel tile, one launch = one part of a frame.
-//
-// Replaces, fused into a single kernel, the reference's per-pixel loop and everything under it:
-//   Code/main.cpp:281-322 (sample loop, average, tone map, 8-bit), Code/environment/camera.cpp:89-135 (rays),
-//   Code/utilities/tracer.h:147-308 (Whitted recursion -> bounded pending-ray stack), Code/utilities/shading.h
-//   (Blinn-Phong, soft shadows with coloured transmission), Code/acceleration/{bvh,aabb}.cpp (traversal),
-//   Code/shapes/*.cpp (sphere / quad / cube / displaced shapes), Code/utilities/Image.cpp + HDRImage.cpp (lookups).
-//
-// Arithmetic is FP64 throughout (the parity bar is 8-bit max|diff| <= 1 against an FP64 reference); compiled with
-// -ffp-contract=off so that sums and products round where the reference's do.
+// Device-side building blocks shared by the render kernels (render_wavefront.hip, render_mega.hip): FP64 vector
+// algebra, RNG, texture / environment lookups, primitive tests, BVH traversal step helpers and hit-record
+// reconstruction.  Every function cites the reference code it reproduces (paths relative to /root/reference/Code).
+// Arithmetic is FP64 throughout (the parity bar is 8-bit max|diff| <= 1 against an FP64 reference); the including
+// translation units are compiled with -ffp-contract=off so that sums and products round where the reference's do.
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
-#include "render_kernel.h"
 
 namespace rt {
 
 namespace {
 
-constexpr int kBlock = 256;            // 4 waves; each wave owns an 8x8 pixel tile, a block a 32x8 strip
 constexpr double kPi = 3.14159265358979323846;
 
 // ------------------------------------------------------------------------------------------ small vector algebra
@@ -309,7 +303,7 @@ __device__ __forceinline__ bool slab_range(D3 oo, D3 od, D3 b, double& tn, doubl
 }
 
 // Ray-marched displaced shapes (complex_sphere.cpp:30-168, complex_cube.cpp:121-278, complex_plane.cpp:112-233).
-__device__ __noinline__ bool march_complex(const DScene& S, const DParams& P, const DPrim& pr, const Ray& r, double tmin, double tmax,
+__device__ bool march_complex(const DScene& S, const DParams& P, const DPrim& pr, const Ray& r, double tmin, double tmax,
                                            double& t_out) {
     const DXform& X = S.xforms[pr.data];
     const DMaterial& M = S.materials[pr.material];
@@ -351,8 +345,28 @@ __device__ __noinline__ bool march_complex(const DScene& S, const DParams& P, co
     return false;
 }
 
+// Per-lane traversal stack living in LDS: entry i of this lane is base[i * stride] (stride = threads per block, so
+// that the lanes of a wave hit 64 consecutive banks).
+struct TravStack {
+    int* base;
+    int stride;
+    __device__ __forceinline__ int& at(int i) const { return base[i * stride]; }
+};
+
 struct Counters {
     unsigned int rays, nodes, prims;
+};
+
+// Compile-time feature set of a kernel variant (RT_FEAT_* bits of device_types.h).  A scene is rendered by the
+// smallest variant that covers scene.features, so that e.g. a spheres-only BVH stress frame does not carry the
+// registers of the ray marcher or the texture paths.
+template <int F> struct Feat {
+    static constexpr bool quad = (F & RT_FEAT_QUAD) != 0;
+    static constexpr bool cube = (F & RT_FEAT_CUBE) != 0;
+    static constexpr bool complex_ = (F & RT_FEAT_COMPLEX) != 0;
+    static constexpr bool tex = (F & RT_FEAT_TEXTURE) != 0;
+    static constexpr bool env = (F & RT_FEAT_ENV) != 0;
+    static constexpr bool sphere = (F & RT_FEAT_SPHERE) != 0;
 };
 
 // Tie rule.  The reference visits primitives in a fixed order and replaces the current hit when a later test
@@ -366,6 +380,7 @@ __device__ __forceinline__ bool tie_new_wins(bool new_incl, int new_order, bool 
 }
 
 // One primitive against the ray; updates `best` when it is the new closest hit.
+template <int F>
 __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, const Ray& r, int prim, int order, double tmin,
                                           Cand& best, int& best_order, bool& best_incl, Counters& C) {
     const DPrim pr = S.prims[prim];
@@ -374,7 +389,7 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
     int tri = 0;
     bool hit = false, incl = true;
     const double tmax = best.t;
-    if (pr.type == RT_SHAPE_SPHERE) {  // sphere.cpp:44-90
+    if (Feat<F>::sphere && pr.type == RT_SHAPE_SPHERE) {  // sphere.cpp:44-90
         const DXform& X = S.xforms[pr.data];
         ObjRay q = to_object(X, r);
         double a = dot(q.d, q.d), b = 2.0 * dot(q.o, q.d), c = dot(q.o, q.o) - 1.0;
@@ -389,7 +404,7 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
             }
             t = root;
         }
-    } else if (pr.type == RT_SHAPE_PLANE) {  // plane.cpp:137-177
+    } else if (Feat<F>::quad && pr.type == RT_SHAPE_PLANE) {  // plane.cpp:137-177
         const DQuad& Q = S.quads[pr.data];
         D3 o0 = r.o - ld3(Q.vel) * r.time;
         double t1, u1, v1, t2, u2, v2;
@@ -404,7 +419,7 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
             bu = first ? u1 : u2;
             bv = first ? v1 : v2;
         }
-    } else if (pr.type == RT_SHAPE_CUBE) {  // cube.cpp:25-89
+    } else if (Feat<F>::cube && pr.type == RT_SHAPE_CUBE) {  // cube.cpp:25-89
         const DXform& X = S.xforms[pr.data];
         ObjRay q = to_object(X, r);
         double tn = -INFINITY, tf = INFINITY;
@@ -438,7 +453,7 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
             }
             t = th;
         }
-    } else {
+    } else if (Feat<F>::complex_) {
         hit = march_complex(S, P, pr, r, tmin, tmax, t);
     }
     if (!hit) return;
@@ -477,8 +492,9 @@ __device__ __forceinline__ bool box_test(const double* lo, const double* hi, con
 // Closest hit == `world.intersect(r, tmin, tmax, rec)` (hittable_list.cpp:8-33 over bvh.cpp:101-114).
 // Traversal is front-to-back with a per-lane stack of deferred children in LDS; the hit found equals the
 // reference's left-then-right recursion because closest-hit selection is order independent (ties: tie_new_wins).
+template <int F>
 __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, double tmin, double tmax, Cand& best, Counters& C,
-                            int (*stack)[kBlock]) {
+                            TravStack stack) {
     C.rays++;
     best.t = tmax;
     best.prim = -1;
@@ -488,7 +504,7 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
     bool best_incl = false;
     if (S.n_prims <= 0) return false;
     if (!P.use_bvh) {  // --no-bvh: the list in scene-file order
-        for (int i = 0; i < S.n_prims; ++i) test_prim(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+        for (int i = 0; i < S.n_prims; ++i) test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
         return best.prim >= 0;
     }
     const double o[3] = {r.o.x, r.o.y, r.o.z};
@@ -496,11 +512,14 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
     double e;
     if (P.count_tests) C.nodes++;
     if (!box_test(S.root_lo, S.root_hi, o, inv, tmin, tmax, e)) return false;
-    const int tid = threadIdx.x;
     int sp = 0;
     int cur = S.root_ref;
-    while (true) {
-        if (cur >= 0) {
+    constexpr int kDone = 0x7fffffff;
+    // "while-while" traversal: every lane first descends interior nodes until it holds a leaf (or runs out of
+    // work); lanes that found their leaf early idle until the whole wave has left the inner loop, so that the
+    // expensive FP64 primitive tests below run with many lanes active instead of once per node step.
+    while (cur != kDone) {
+        while (static_cast<unsigned>(cur) < static_cast<unsigned>(kDone)) {  // 0 <= cur < kDone: interior node
             const DNode* n = &S.nodes[cur];
             if (P.count_tests) C.nodes += 2;
             double e0, e1;
@@ -509,20 +528,23 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
             int c0 = n->child[0], c1 = n->child[1];
             if (h0 && h1) {
                 bool left_first = !(e1 < e0);
-                stack[sp++][tid] = left_first ? c1 : c0;
+                stack.at(sp++) = left_first ? c1 : c0;
                 cur = left_first ? c0 : c1;
-                continue;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else {
+                cur = sp ? stack.at(--sp) : kDone;
             }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else {
+        }
+        if (cur < 0) {  // leaf: one or two consecutive primitives
             int code = ~cur;
             int first = code >> 1;
-            test_prim(S, P, r, first, first, tmin, best, best_order, best_incl, C);
-            if (code & 1) test_prim(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+            test_prim<F>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
+            if (code & 1) test_prim<F>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+            cur = sp ? stack.at(--sp) : kDone;
         }
-        if (sp == 0) break;
-        cur = stack[--sp][tid];
     }
     return best.prim >= 0;
 }
@@ -554,6 +576,7 @@ __device__ D3 bump_nearest(const DTexture& T, D3 N, double u, double v) {
 }
 
 // Everything the shapes' intersect() write into the HitRecord, recomputed for the winning candidate only.
+template <int F>
 __device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const Cand& c, Hit& h) {
     const DPrim pr = S.prims[c.prim];
     const DMaterial& M = S.materials[pr.material];
@@ -562,8 +585,8 @@ __device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const 
     h.material = pr.material;
     h.u = 0.0;
     h.v = 0.0;
-    const bool need_uv = (M.texture >= 0) || (M.bump >= 0);
-    if (pr.type == RT_SHAPE_SPHERE) {  // sphere.cpp:92-171
+    const bool need_uv = Feat<F>::tex && ((M.texture >= 0) || (M.bump >= 0));
+    if (Feat<F>::sphere && pr.type == RT_SHAPE_SPHERE) {  // sphere.cpp:92-171
         const DXform& X = S.xforms[pr.data];
         ObjRay q = to_object(X, r);
         D3 on = (q.o + (c.t * q.d)) - mk(0, 0, 0);
@@ -573,12 +596,12 @@ __device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const 
             if (M.bump >= 0) outward = bump_nearest(S.textures[M.bump], outward, h.u, h.v);
         }
         set_face_normal(h, r, outward);
-    } else if (pr.type == RT_SHAPE_PLANE) {  // plane.cpp:179-243
+    } else if (Feat<F>::quad && pr.type == RT_SHAPE_PLANE) {  // plane.cpp:179-243
         const DQuad& Q = S.quads[pr.data];
         D3 n = ld3(Q.n), outward = n;
         if (c.tri == 0) { h.u = c.bu; h.v = c.bv; }
         else { h.u = 1.0 - c.bv; h.v = c.bu + c.bv; }
-        if (M.bump >= 0) {
+        if (Feat<F>::tex && M.bump >= 0) {
             const DTexture& T = S.textures[M.bump];
             D3 Tn = normalize(ld3(Q.e1)), B = normalize(ld3(Q.e2));
             int w = T.width, hh = T.height;
@@ -592,7 +615,7 @@ __device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const 
             outward = normalize(n + (Tn * bu + B * bv) * 0.0075);
         }
         set_face_normal(h, r, outward);
-    } else if (pr.type == RT_SHAPE_CUBE) {  // cube.cpp:91-231
+    } else if (Feat<F>::cube && pr.type == RT_SHAPE_CUBE) {  // cube.cpp:91-231
         const DXform& X = S.xforms[pr.data];
         ObjRay q = to_object(X, r);
         D3 p = q.o + q.d * c.t, on;
@@ -601,9 +624,9 @@ __device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const 
         D3 outward = normal_to_world(X, on);
         h.u = u;
         h.v = v;
-        if (M.bump >= 0) outward = bump_nearest(S.textures[M.bump], outward, u, v);
+        if (Feat<F>::tex && M.bump >= 0) outward = bump_nearest(S.textures[M.bump], outward, u, v);
         set_face_normal(h, r, outward);
-    } else {  // complex_*.cpp: uv at the marched point, central-difference normal (step 0.005)
+    } else if (Feat<F>::complex_) {  // complex_*.cpp: uv at the marched point, central-difference normal (step 0.005)
         const DXform& X = S.xforms[pr.data];
         ObjRay q = to_object(X, r);
         D3 p = q.o + q.d * c.t;
@@ -618,111 +641,8 @@ __device__ void fill_hit(const DScene& S, const DParams& P, const Ray& r, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------ shading (shading.h)
-// shading.h:42-75, the recursion through transparent occluders unrolled into a loop (each level multiplies the
-// running transmission by its own tint; the < 0.001 cut-off is applied to the level's own factor, as there).
-__device__ D3 shadow_transmission(const DScene& S, const DParams& P, Ray sr, double dist, Counters& C, int (*stack)[kBlock]) {
-    D3 total = mk(1.0, 1.0, 1.0);
-    for (int seg = 0; seg < kShadowMaxSegments; ++seg) {
-        Cand c;
-        if (!closest_hit(S, P, sr, 0.001, dist - 0.001, c, C, stack)) return total;
-        Hit h;
-        fill_hit(S, P, sr, c, h);
-        const DMaterial& M = S.materials[h.material];
-        if (!(M.transparency > 0.0)) return mk(0, 0, 0);
-        double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
-        double eta = n1 / n2;
-        double cos_i = -dot(sr.d, h.n);
-        double sin2 = eta * eta * (1.0 - cos_i * cos_i);
-        if (sin2 > 1.0) return mk(0, 0, 0);
-        double r0 = ((n1 - n2) / (n1 + n2));
-        r0 = r0 * r0;
-        double refl = r0 + (1.0 - r0) * pow((1.0 - cos_i), 5.0);  // shadow_schlick, shading.h:24-28
-        D3 local = cmul(mk(1.0, 1.0, 1.0), ld3(M.diffuse)) * (1.0 - refl);
-        if (length(local) < 0.001) return mk(0, 0, 0);
-        total = cmul(total, local);
-        sr.o = h.p + sr.d * 0.001;
-        dist = dist - h.t;
-    }
-    return total;
-}
-
-// shading.h:79-101
-__device__ D3 light_visibility(const DScene& S, const DParams& P, const DLight& L, D3 Pt, D3 N, double time, Rng& rng, Counters& C,
-                               int (*stack)[kBlock]) {
-    if (!P.shadows) return mk(1.0, 1.0, 1.0);
-    D3 acc = mk(0, 0, 0);
-    for (int i = 0; i < P.shadow_samples; ++i) {
-        D3 lp = ld3(L.pos);
-        if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
-        D3 d = lp - Pt;
-        double dist = length(d);
-        d = normalize(d);
-        Ray sr{Pt + N * P.eps_shadow, d, time};
-        acc = acc + shadow_transmission(S, P, sr, dist, C, stack);
-    }
-    return acc * (1.0 / P.shadow_samples);
-}
-
-// shading.h:104-175 (ambient + diffuse) and shading.h:181-217 (specular); visibility is evaluated separately for
-// each, as the reference does.
-__device__ void shade_local(const DScene& S, const DParams& P, const Hit& h, const Ray& view, Rng& rng, Counters& C,
-                            int (*stack)[kBlock], D3& ad, D3& spec) {
-    const DMaterial& M = S.materials[h.material];
-    D3 base;
-    if (M.texture >= 0) {
-        const DTexture& T = S.textures[M.texture];
-        int x = to_int(h.u * (T.width - 1)), y = to_int((1.0 - h.v) * (T.height - 1));
-        x = imin(imax(x, 0), T.width - 1);
-        y = imin(imax(y, 0), T.height - 1);
-        Px p = tex_get(T, x, y);
-        base = mk(p.r / 255.0, p.g / 255.0, p.b / 255.0);
-    } else {
-        base = ld3(M.diffuse);
-    }
-    D3 colour = cmul(cmul(ld3(M.ambient), ld3(P.ambient_light)), base);
-    const D3 Pt = h.p, N = normalize(h.n);
-    for (int li = 0; li < S.n_lights; ++li) {
-        const DLight& L = S.lights[li];
-        D3 vis = light_visibility(S, P, L, Pt, N, view.time, rng, C, stack);
-        if (vis.x > 0 || vis.y > 0 || vis.z > 0) {
-            D3 Lr = ld3(L.pos) - Pt;
-            double falloff = 1.0 / dot(Lr, Lr);
-            D3 Ld = normalize(Lr);
-            D3 I = ld3(L.intensity) * falloff * P.exposure;
-            double ldn = smax(0.0, dot(Ld, N));
-            D3 diff = cmul(base, I) * ldn;
-            diff = diff * (1.0 - M.transparency);
-            colour = colour + cmul(diff, vis);
-        }
-    }
-    ad = colour;
-    const D3 V = normalize(view.o - Pt);
-    D3 sp = mk(0, 0, 0);
-    for (int li = 0; li < S.n_lights; ++li) {
-        const DLight& L = S.lights[li];
-        D3 vis = light_visibility(S, P, L, Pt, N, view.time, rng, C, stack);
-        if (length(vis) > 0) {
-            D3 Lr = ld3(L.pos) - Pt;
-            double falloff = 1.0 / dot(Lr, Lr);
-            D3 Ld = normalize(Lr);
-            D3 Hv = normalize(Ld + V);
-            D3 I = ld3(L.intensity) * falloff * P.exposure;
-            double hdn = smax(0.0, dot(Hv, N));
-            D3 part = cmul(ld3(M.specular), I) * exp(M.shininess * log(hdn));  // fast_pow, shading.h:177
-            sp = sp + cmul(part, vis);
-        }
-    }
-    spec = sp;
-}
-
 // ------------------------------------------------------------------------------------------ integrator (tracer.h)
 __device__ __forceinline__ D3 reflect(D3 V, D3 N) { return V - 2 * dot(V, N) * N; }  // tracer.h:57-60
-
-struct Pending {   // one not-yet-traced ray of the Whitted tree: colour contribution = weight (x) ray_colour(ray, depth)
-    D3 o, d, w;
-    int depth;
-};
 
 // camera.cpp:89-135
 __device__ Ray generate_ray(const DCamera& c, float px, float py, double time, Rng& rng) {
@@ -757,172 +677,6 @@ __device__ __forceinline__ unsigned char quantise(double v) {  // tracer.h:297-3
     return (unsigned char)(255 * c);
 }
 
-// ray_colour(ray, depth) of tracer.h:147-295 as a loop over a per-lane stack of pending rays.  The colour of a hit is
-// linear in the colours of its child rays, so each child carries the product of the weights above it and every
-// visited hit adds weight (x) local term to the pixel.
-__device__ D3 trace(const DScene& S, const DParams& P, const Ray& primary, Rng& rng, Counters& C, int (*tstack)[kBlock]) {
-    Pending stack[kRayStackDepth];
-    int sp = 0;
-    D3 accum = mk(0, 0, 0);
-    stack[sp++] = Pending{primary.o, primary.d, mk(1.0, 1.0, 1.0), P.max_depth};
-    const double eps = P.eps_scene;
-    const double time = primary.time;
-    while (sp > 0) {
-        Pending cur = stack[--sp];
-        if (cur.depth <= 0) continue;  // tracer.h:149
-        Ray r{cur.o, cur.d, time};
-        Cand c;
-        if (!closest_hit(S, P, r, eps, 100000.0, c, C, tstack)) {
-            D3 bg = S.env_present ? env_sample(S, r.d) : ld3(P.background);  // tracer.h:282-293
-            accum = accum + cmul(cur.w, bg);
-            continue;
-        }
-        Hit h;
-        fill_hit(S, P, r, c, h);
-        if (P.normals) {  // tracer.h:157-161
-            accum = accum + cmul(cur.w, (h.n + mk(1, 1, 1)) * 0.5);
-            continue;
-        }
-        D3 ad, spec;
-        shade_local(S, P, h, r, rng, C, tstack, ad, spec);
-        const DMaterial& M = S.materials[h.material];
-        const bool transparent = M.transparency > 0;
-        bool has_refl = M.reflectivity > 0;
-        if (transparent && P.fresnel) has_refl = true;
-
-        double reflect_prob = M.reflectivity, transmit_prob = M.transparency;
-        bool do_refract = false, tir_mirror = false;
-        D3 refr_dir = mk(0, 0, 0), Vin = mk(0, 0, 0), Nh = mk(0, 0, 0);
-        if (transparent) {  // tracer.h:226-266 with compute_refraction tracer.h:100-143
-            Vin = normalize(r.d);
-            Nh = normalize(h.n);
-            double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
-            double eta = n1 / n2;
-            double cos_i = -dot(Vin, Nh);
-            double sin2 = eta * eta * (1.0 - cos_i * cos_i);
-            if (sin2 > 1.0) {
-                transmit_prob = 0.0;
-                reflect_prob = 1.0;
-                tir_mirror = !has_refl;
-            } else {
-                double cos_t = sqrt(1.0 - sin2);
-                refr_dir = (eta * Vin) + (eta * cos_i - cos_t) * Nh;
-                do_refract = true;
-                if (P.fresnel) {
-                    double r0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));  // schlick, tracer.h:88-97
-                    double x = 1.0 - cos_i;
-                    reflect_prob = r0 + (1.0 - r0) * (x * x * x * x * x);
-                    transmit_prob = 1.0 - reflect_prob;
-                }
-            }
-        }
-        // tracer.h:268-279
-        D3 local;
-        double refl_weight;
-        if (transparent) { local = spec; refl_weight = reflect_prob; }
-        else { local = ad * (1.0 - M.reflectivity) + spec; refl_weight = M.reflectivity; }
-        accum = accum + cmul(cur.w, local);
-
-        const int child_depth = cur.depth - 1;
-        if (child_depth <= 0) continue;  // children would return black without tracing (tracer.h:149)
-        if (has_refl) {  // tracer.h:176-219
-            int samples = P.glossy_samples;
-            if (cur.depth < P.max_bounces) samples = 1;
-            double rough = 1.0 / sqrt(M.shininess);
-            D3 V = normalize(r.d);
-            D3 perfect = normalize(reflect(V, h.n));
-            D3 wr = cur.w * refl_weight;
-            if (M.is_metal) wr = cmul(wr, ld3(M.diffuse));
-            D3 org = h.p + h.n * eps;
-            if (samples > 0) {
-                wr = wr * (1.0 / samples);
-                for (int i = 0; i < samples; ++i) {
-                    D3 off = rng.in_unit_sphere() * rough;
-                    D3 target = normalize(perfect + off);
-                    if (dot(target, h.n) > 0 && sp < kRayStackDepth) stack[sp++] = Pending{org, target, wr, child_depth};
-                }
-            } else if (sp < kRayStackDepth) {
-                stack[sp++] = Pending{org, perfect, wr, child_depth};
-            }
-        }
-        if (tir_mirror && sp < kRayStackDepth)  // tracer.h:258-264 (not tinted for metals)
-            stack[sp++] = Pending{h.p + Nh * eps, normalize(reflect(Vin, Nh)), cur.w * reflect_prob, child_depth};
-        if (do_refract && sp < kRayStackDepth)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
-            stack[sp++] = Pending{h.p, normalize(refr_dir), cmul(cur.w * transmit_prob, ld3(M.diffuse)), child_depth};
-    }
-    return accum;
-}
-
-// ------------------------------------------------------------------------------------------ the kernel
-__global__ void __launch_bounds__(kBlock) k_render(const DScene S, const DParams P, uint8_t* __restrict__ out,
-                                                   unsigned long long* __restrict__ counters) {
-    __shared__ int tstack[kTravStackDepth][kBlock];
-
-    // XCD-aware block order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
-    // L2); remap so that every XCD works on one contiguous run of image tiles and re-uses the BVH nodes it pulled in.
-    const int nblk = gridDim.x;
-    const int q = nblk / 8, rem = nblk % 8;
-    const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
-    const int blk = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + within;
-
-    const int blocks_x = (P.width + 31) / 32;
-    const int bx = blk % blocks_x, by = blk / blocks_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = bx * 32 + wave * 8 + (lane & 7);
-    const int lr = by * 8 + (lane >> 3);   // row inside this part's compact slice
-    const bool active = (x < P.width) && (lr < P.part_rows);
-
-    Counters C{0u, 0u, 0u};
-    if (active) {
-        // compact row -> frame row: tile k of the slice is frame tile k*part_count + part_index
-        const int y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
-        D3 acc = mk(0, 0, 0);
-        for (int s = 0; s < P.spp; ++s) {  // main.cpp:288-306
-            Rng rng;
-            rng.d0 = (P.rng_mode == RT_RNG_D0);
-            rng.s = (P.seed * 0x9E3779B97F4A7C15ull) ^
-                    (((unsigned long long)y * P.width + x) * 0xD1B54A32D192ED03ull + (unsigned long long)s * 0x8CB92BA72F3D8DD7ull);
-            float ru = (float)rng.uniform(), rv = (float)rng.uniform();
-            float px = ((float)x + ru) / (float)P.width;
-            float py = ((float)y + rv) / (float)P.height;
-            double time = rng.uniform() * S.shutter_time;
-            Ray ray = generate_ray(S.cam, px, py, time, rng);
-            acc = acc + trace(S, P, ray, rng, C, tstack);
-        }
-        D3 avg = tonemap(acc * (1.0 / P.spp), P.tonemap);  // main.cpp:308-316
-        uint8_t* o = out + ((size_t)lr * P.width + x) * 3;
-        o[0] = quantise(avg.x);
-        o[1] = quantise(avg.y);
-        o[2] = quantise(avg.z);
-    }
-    if (counters) {  // one atomic per wave and counter
-        unsigned int rays = C.rays, nodes = C.nodes, prims = C.prims;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            rays += __shfl_down(rays, off);
-            nodes += __shfl_down(nodes, off);
-            prims += __shfl_down(prims, off);
-        }
-        if (lane == 0) {
-            atomicAdd(&counters[0], (unsigned long long)rays);
-            if (P.count_tests) {
-                atomicAdd(&counters[1], (unsigned long long)nodes);
-                atomicAdd(&counters[2], (unsigned long long)prims);
-            }
-        }
-    }
-}
-
 }  // namespace
-
-hipError_t launch_render(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                         hipStream_t stream) {
-    const int blocks_x = (params.width + 31) / 32;
-    const int blocks_y = (params.part_rows + 7) / 8;
-    const int nblk = blocks_x * blocks_y;
-    if (nblk <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_render, dim3(nblk), dim3(kBlock), 0, stream, scene, params, d_rgb8, d_counters);
-    return hipGetLastError();
-}
 
 }  // namespace rt

@@ -1,16 +1,39 @@
-// Host-callable launcher of the render kernel (render_kernel.hip).
+// Host-callable launchers of the render kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "device_types.h"
 
 namespace rt {
 
-// Renders this part's rows (params.part_rows rows of params.width pixels, compact, tile order) into d_rgb8 on
-// `stream`.  d_counters: NULL or 4 x u64 {rays, node visits, primitive tests, reserved} that the kernel adds into.
-hipError_t launch_render(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                         hipStream_t stream);
+// Megakernel schedule (render_mega.hip): renders this part's rows (params.part_rows rows of params.width pixels,
+// compact, tile order) into d_rgb8 with one launch on `stream`.  d_counters: NULL or 4 x u64 {rays, box tests,
+// primitive tests, reserved} that the kernel adds into.
+hipError_t launch_render_mega(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
+                              hipStream_t stream);
+
+// Device memory the wavefront schedule keeps between calls (owned by the scene; freed with the scene).
+struct WavefrontWorkspace {
+    size_t capacity = 0;                 // rays per queue
+    std::vector<void*> queues;           // RayRec[capacity] each
+    std::vector<void*> hit_buffers;      // HitRec[capacity] each, paired with queues
+    std::vector<char> in_use;
+    double* accum = nullptr;             // FP64 RGB accumulator per pixel of the part
+    size_t accum_pixels = 0;
+    unsigned* counters = nullptr;        // [0] next ray to fetch, [1] rays emitted, [2] overflow flag
+    unsigned long long* stats = nullptr; // [1] box tests, [2] primitive tests
+    unsigned long long host_counts[4] = {0, 0, 0, 0};
+    int compute_units = 256;
+};
+void wavefront_workspace_free(WavefrontWorkspace& ws);
+
+// Wavefront schedule (render_wavefront.hip): same pixels; work is enqueued on `stream`, and the call returns after the
+// last queue has been drained (it reads queue sizes back between levels).
+hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
+                                   hipStream_t stream, WavefrontWorkspace& ws);
 
 }  // namespace rt

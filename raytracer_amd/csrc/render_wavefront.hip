@@ -1,0 +1,611 @@
+// Wavefront schedule of the render path: the Whitted tree of every pixel is evaluated breadth-first as queues of rays
+// in HBM, so that the two very different kinds of work run in kernels of their own:
+//
+//   k_raygen    camera rays (AA jitter, lens sample, ray time)                -> ray queue       camera.cpp:89-135, main.cpp:288-302
+//   k_traverse  closest hit of every queued ray through the flattened BVH     -> hit records     bvh.cpp:101-114, aabb.cpp:4-38, shapes/*.cpp
+//   k_shade     hit -> Blinn-Phong terms, shadow / reflection / refraction    -> next ray queue, tracer.h:147-295, shading.h:42-217
+//               rays carrying their colour weight; local terms added to the      FP64 accumulators
+//               pixel accumulator
+//   k_resolve   average, tone map, 8-bit                                      -> RGB8 rows       main.cpp:308-320, tracer.h:23-54,297-308
+//
+// Why: on the 10^6-sphere frame a lane's traversal length varies by an order of magnitude inside one 8x8 tile, and a
+// one-lane-per-pixel megakernel idles 85 % of its lanes (measured).  k_traverse is a persistent kernel:
+// lanes that finish their ray immediately fetch the next one from the queue, and a wave votes on whether to spend the
+// next step on interior nodes or on the (much more expensive, FP64 sqrt/div) primitive tests.  Its register budget
+// is the ray, the best hit and two child boxes, which lets 2x as many waves stay resident as the megakernel's.
+//
+// The colour of a ray is linear in the colours of its child rays (tracer.h:268-279) and in the visibility of each
+// light (shading.h:166-171, 206-211), so every queued ray carries the product of the weights above it and adds
+// weight (x) result to its pixel when it terminates; no per-pixel recursion state is kept.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "device_rt.h"
+#include "render_kernel.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kKindRadiance = 0, kKindShadow = 1;
+
+struct alignas(16) RayRec {
+    double o[3], d[3], w[3];   // origin, direction, colour weight of whatever this ray returns
+    double time;
+    double tmax;               // radiance: 1e5 (tracer.h:156); shadow: distance to the light sample (shading.h:45)
+    unsigned long long rng;    // state of this ray's random stream
+    int pixel;                 // accumulator index inside this part
+    short depth;               // remaining depth (tracer.h:149) for radiance rays
+    short kind;
+};
+static_assert(sizeof(RayRec) == 112, "RayRec size");
+
+struct alignas(16) HitRec {
+    double t, bu, bv;
+    int prim, tri;
+};
+static_assert(sizeof(HitRec) == 32, "HitRec size");
+
+struct Chunk {
+    int row0, rows;     // compact rows [row0, row0 + rows) of this part
+    int s0, ns;         // samples [s0, s0 + ns) of every pixel
+};
+
+__device__ __forceinline__ void accum_add(double* accum, int pixel, D3 c) {
+    unsafeAtomicAdd(&accum[pixel * 3 + 0], c.x);
+    unsafeAtomicAdd(&accum[pixel * 3 + 1], c.y);
+    unsafeAtomicAdd(&accum[pixel * 3 + 2], c.z);
+}
+
+// Reserve one output slot for every lane that calls this (wave-aggregated: one atomic per wave and call site).
+__device__ __forceinline__ unsigned emit_slot(unsigned* count) {
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void emit_ray(RayRec* out, unsigned* count, unsigned cap, unsigned* overflow, D3 o, D3 d, D3 w, double time,
+                                         double tmax, unsigned long long rng, int pixel, int depth, int kind) {
+    unsigned slot = emit_slot(count);
+    if (slot >= cap) { *overflow = 1u; return; }   // the host sizes batches so that this cannot happen; it checks the flag
+    RayRec r;
+    r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
+    r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
+    r.w[0] = w.x; r.w[1] = w.y; r.w[2] = w.z;
+    r.time = time; r.tmax = tmax; r.rng = rng; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
+    out[slot] = r;
+}
+
+// ------------------------------------------------------------------------------------------ k_raygen
+// Linear index -> pixel of the chunk, in 8-row bands of 8-wide tiles, so that 64 consecutive rays form an 8x8 tile.
+__device__ __forceinline__ void pixel_of(long long pix, int W, int rows, int& x, int& ly) {
+    const int nb = (rows + 7) / 8;
+    int b = (int)(pix / ((long long)W * 8));
+    if (b > nb - 1) b = nb - 1;
+    const int hb = (b == nb - 1) ? rows - 8 * b : 8;
+    int j = (int)(pix - (long long)b * W * 8);
+    const int tiles_x = (W + 7) / 8;
+    int tx = j / (8 * hb);
+    if (tx > tiles_x - 1) tx = tiles_x - 1;
+    const int rem = j - tx * 8 * hb;
+    const int tw = (8 * tx + 8 <= W) ? 8 : W - 8 * tx;
+    ly = b * 8 + rem / tw;
+    x = tx * 8 + rem % tw;
+}
+
+__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const Chunk ck, RayRec* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const long long pix = i / ck.ns;
+    const int s = ck.s0 + (int)(i % ck.ns);
+    int x, ly;
+    pixel_of(pix, P.width, ck.rows, x, ly);
+    const int lr = ck.row0 + ly;
+    const int y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
+    Rng rng;  // main.cpp:288-302
+    rng.d0 = (P.rng_mode == RT_RNG_D0);
+    rng.s = (P.seed * 0x9E3779B97F4A7C15ull) ^
+            (((unsigned long long)y * P.width + x) * 0xD1B54A32D192ED03ull + (unsigned long long)s * 0x8CB92BA72F3D8DD7ull);
+    float ru = (float)rng.uniform(), rv = (float)rng.uniform();
+    float px = ((float)x + ru) / (float)P.width;
+    float py = ((float)y + rv) / (float)P.height;
+    double time = rng.uniform() * S.shutter_time;
+    Ray ray = generate_ray(S.cam, px, py, time, rng);
+    RayRec r;
+    r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z;
+    r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z;
+    r.w[0] = r.w[1] = r.w[2] = 1.0;
+    r.time = time; r.tmax = 100000.0; r.rng = rng.next(); r.pixel = lr * P.width + x; r.depth = (short)P.max_depth; r.kind = kKindRadiance;
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------ k_traverse
+#ifndef RT_TRAVERSE_WAVES
+#define RT_TRAVERSE_WAVES 6       // waves per SIMD asked of the register allocator
+#endif
+#ifndef RT_NODE_VOTE
+#define RT_NODE_VOTE 24           // run an interior-node step while at least this many lanes want one
+#endif
+#ifndef RT_REFILL_VOTE
+#define RT_REFILL_VOTE 16         // fetch new rays once this many lanes are idle
+#endif
+
+template <int F>
+__global__ void __launch_bounds__(kBlock, RT_TRAVERSE_WAVES)
+k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, HitRec* __restrict__ hits, const unsigned n,
+           unsigned* __restrict__ next, unsigned long long* __restrict__ counters) {
+    __shared__ int stack_mem[kTravStackDepth][kBlock];
+    const TravStack stack{&stack_mem[0][threadIdx.x], kBlock};
+    const int lane = threadIdx.x & 63;
+    constexpr int kDone = 0x7fffffff;
+
+    bool active = false, exhausted = false;
+    unsigned my = 0;
+    Ray r{mk(0, 0, 0), mk(0, 0, 1), 0.0};
+    double o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    double tmin = 0.0;
+    Cand best{0.0, -1, 0, 0.0, 0.0};
+    int best_order = 0, sp = 0, cur = kDone;
+    bool best_incl = false;
+    Counters C{0u, 0u, 0u};
+
+    while (true) {
+        // ---- refill idle lanes with the next rays of the queue
+        const unsigned long long idle = __ballot(!active);
+        if (!exhausted && idle != 0ull && (__popcll(idle) >= RT_REFILL_VOTE || idle == ~0ull)) {
+            const int cnt = __popcll(idle);
+            const int leader = __ffsll((long long)idle) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(next, (unsigned)cnt);
+            base = __shfl(base, leader);
+            if (base + (unsigned)cnt >= n) exhausted = true;
+            if (!active) {
+                my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (my < n) {
+                    const RayRec q = rays[my];
+                    r.o = ld3(q.o);
+                    r.d = ld3(q.d);
+                    r.time = q.time;
+                    const bool shadow = q.kind == kKindShadow;
+                    tmin = shadow ? 0.001 : P.eps_scene;                       // shading.h:45 / tracer.h:152-156
+                    const double tmax = shadow ? q.tmax - 0.001 : q.tmax;
+                    best = Cand{tmax, -1, 0, 0.0, 0.0};
+                    best_order = 0;
+                    best_incl = false;
+                    sp = 0;
+                    cur = kDone;
+                    active = true;
+                    if (S.n_prims > 0) {
+                        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+                        inv[0] = 1.0 / r.d.x; inv[1] = 1.0 / r.d.y; inv[2] = 1.0 / r.d.z;
+                        if (P.use_bvh) {
+                            double e;
+                            if (P.count_tests) C.nodes++;
+                            if (box_test(S.root_lo, S.root_hi, o, inv, tmin, tmax, e)) cur = S.root_ref;
+                        } else {  // --no-bvh: the list in scene-file order (hittable_list.cpp:8-33)
+                            for (int i = 0; i < S.n_prims; ++i) test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one step for the wave: interior nodes while enough lanes want them, otherwise the pending leaves
+        const bool is_node = active && static_cast<unsigned>(cur) < static_cast<unsigned>(kDone);
+        const bool is_leaf = active && cur < 0;
+        const unsigned long long mn = __ballot(is_node), ml = __ballot(is_leaf);
+        if (mn != 0ull && (__popcll(mn) >= RT_NODE_VOTE || ml == 0ull)) {
+            if (is_node) {
+                const DNode* nd = &S.nodes[cur];
+                if (P.count_tests) C.nodes += 2;
+                double e0, e1;
+                const bool h0 = box_test(nd->lo[0], nd->hi[0], o, inv, tmin, best.t, e0);
+                const bool h1 = box_test(nd->lo[1], nd->hi[1], o, inv, tmin, best.t, e1);
+                const int c0 = nd->child[0], c1 = nd->child[1];
+                if (h0 && h1) {
+                    const bool left_first = !(e1 < e0);
+                    stack.at(sp++) = left_first ? c1 : c0;
+                    cur = left_first ? c0 : c1;
+                } else if (h0) {
+                    cur = c0;
+                } else if (h1) {
+                    cur = c1;
+                } else {
+                    cur = sp ? stack.at(--sp) : kDone;
+                }
+            }
+        } else if (ml != 0ull) {
+            if (is_leaf) {
+                const int code = ~cur;
+                const int first = code >> 1;
+                test_prim<F>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
+                if (code & 1) test_prim<F>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+                cur = sp ? stack.at(--sp) : kDone;
+            }
+        }
+        // ---- retire finished rays
+        if (active && cur == kDone) {
+            HitRec h;
+            h.t = best.t; h.bu = best.bu; h.bv = best.bv; h.prim = best.prim; h.tri = best.tri;
+            hits[my] = h;
+            active = false;
+        }
+    }
+    if (counters && P.count_tests) {
+        unsigned nodes = C.nodes, prims = C.prims;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nodes += __shfl_down(nodes, off);
+            prims += __shfl_down(prims, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[1], (unsigned long long)nodes);
+            atomicAdd(&counters[2], (unsigned long long)prims);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ k_shade
+struct EmitCtx {
+    RayRec* out;
+    unsigned* count;
+    unsigned* overflow;
+    unsigned cap;
+};
+
+template <int F>
+__global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayRec* __restrict__ rays,
+                                                  const HitRec* __restrict__ hits, const unsigned n, const EmitCtx E,
+                                                  double* __restrict__ accum) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const RayRec q = rays[i];
+    const HitRec hr = hits[i];
+    const Ray r{ld3(q.o), ld3(q.d), q.time};
+    const D3 w = ld3(q.w);
+    Rng rng{q.rng, P.rng_mode == RT_RNG_D0};
+    const Cand c{hr.t, hr.prim, hr.tri, hr.bu, hr.bv};
+
+    if (q.kind == kKindShadow) {  // shading.h:42-75, one segment of the transmission chain
+        if (c.prim < 0) {  // reached the light sample: this sample's share of the light term
+            accum_add(accum, q.pixel, w);
+            return;
+        }
+        const DPrim pr = S.prims[c.prim];
+        const DMaterial& M = S.materials[pr.material];
+        if (!(M.transparency > 0.0)) return;  // opaque occluder: transmission 0
+        Hit h;
+        fill_hit<F>(S, P, r, c, h);
+        double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
+        double eta = n1 / n2;
+        double cos_i = -dot(r.d, h.n);
+        double sin2 = eta * eta * (1.0 - cos_i * cos_i);
+        if (sin2 > 1.0) return;
+        double r0 = ((n1 - n2) / (n1 + n2));
+        r0 = r0 * r0;
+        double refl = r0 + (1.0 - r0) * pow((1.0 - cos_i), 5.0);  // shadow_schlick, shading.h:24-28
+        D3 local = cmul(mk(1.0, 1.0, 1.0), ld3(M.diffuse)) * (1.0 - refl);
+        if (length(local) < 0.001) return;
+        emit_ray(E.out, E.count, E.cap, E.overflow, h.p + r.d * 0.001, r.d, cmul(w, local), q.time, q.tmax - h.t, rng.next(), q.pixel,
+                 q.depth, kKindShadow);
+        return;
+    }
+
+    // ---- radiance ray: tracer.h:147-295
+    if (c.prim < 0) {
+        D3 bg = (Feat<F>::env && S.env_present) ? env_sample(S, r.d) : ld3(P.background);  // tracer.h:282-293
+        accum_add(accum, q.pixel, cmul(w, bg));
+        return;
+    }
+    Hit h;
+    fill_hit<F>(S, P, r, c, h);
+    if (P.normals) {  // tracer.h:157-161
+        accum_add(accum, q.pixel, cmul(w, (h.n + mk(1, 1, 1)) * 0.5));
+        return;
+    }
+    const DMaterial& M = S.materials[h.material];
+    const bool transparent = M.transparency > 0;
+    bool has_refl = M.reflectivity > 0;
+    if (transparent && P.fresnel) has_refl = true;
+    const double eps = P.eps_scene;
+
+    // refraction geometry first: the weights of the local terms depend on it (tracer.h:226-266, 100-143)
+    double reflect_prob = M.reflectivity, transmit_prob = M.transparency;
+    bool do_refract = false, tir_mirror = false;
+    D3 refr_dir = mk(0, 0, 0), Vin = mk(0, 0, 0), Nh = mk(0, 0, 0);
+    if (transparent) {
+        Vin = normalize(r.d);
+        Nh = normalize(h.n);
+        double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
+        double eta = n1 / n2;
+        double cos_i = -dot(Vin, Nh);
+        double sin2 = eta * eta * (1.0 - cos_i * cos_i);
+        if (sin2 > 1.0) {
+            transmit_prob = 0.0;
+            reflect_prob = 1.0;
+            tir_mirror = !has_refl;
+        } else {
+            double cos_t = sqrt(1.0 - sin2);
+            refr_dir = (eta * Vin) + (eta * cos_i - cos_t) * Nh;
+            do_refract = true;
+            if (P.fresnel) {
+                double r0 = ((n1 - n2) / (n1 + n2)) * ((n1 - n2) / (n1 + n2));  // schlick, tracer.h:88-97
+                double x = 1.0 - cos_i;
+                reflect_prob = r0 + (1.0 - r0) * (x * x * x * x * x);
+                transmit_prob = 1.0 - reflect_prob;
+            }
+        }
+    }
+    // weight of the ambient+diffuse term and of the reflected colour in the final mix (tracer.h:268-279)
+    const double ad_weight = transparent ? 0.0 : (1.0 - M.reflectivity);
+    const double refl_weight = transparent ? reflect_prob : M.reflectivity;
+
+    // ---- local shading: shading.h:104-217
+    D3 base;
+    if (Feat<F>::tex && M.texture >= 0) {
+        const DTexture& T = S.textures[M.texture];
+        int x = to_int(h.u * (T.width - 1)), y = to_int((1.0 - h.v) * (T.height - 1));
+        x = imin(imax(x, 0), T.width - 1);
+        y = imin(imax(y, 0), T.height - 1);
+        Px p = tex_get(T, x, y);
+        base = mk(p.r / 255.0, p.g / 255.0, p.b / 255.0);
+    } else {
+        base = ld3(M.diffuse);
+    }
+    const D3 Pt = h.p, N = normalize(h.n);
+    const D3 V = normalize(r.o - Pt);
+    D3 ad = cmul(cmul(ld3(M.ambient), ld3(P.ambient_light)), base);
+    D3 spec = mk(0, 0, 0);
+    for (int li = 0; li < S.n_lights; ++li) {
+        const DLight& L = S.lights[li];
+        D3 Lr = ld3(L.pos) - Pt;
+        double falloff = 1.0 / dot(Lr, Lr);
+        D3 Ld = normalize(Lr);
+        D3 I = ld3(L.intensity) * falloff * P.exposure;
+        double ldn = smax(0.0, dot(Ld, N));
+        D3 diff = cmul(base, I) * ldn;
+        diff = diff * (1.0 - M.transparency);                                   // shading.h:166-167
+        D3 Hv = normalize(Ld + V);
+        double hdn = smax(0.0, dot(Hv, N));
+        D3 sp = cmul(ld3(M.specular), I) * exp(M.shininess * log(hdn));        // shading.h:206, fast_pow :177
+        if (!P.shadows) {  // visibility (1,1,1), shading.h:80
+            ad = ad + cmul(diff, mk(1.0, 1.0, 1.0));
+            spec = spec + cmul(sp, mk(1.0, 1.0, 1.0));
+        } else {
+            // compute_light_visibility (shading.h:79-101) is evaluated once for the diffuse and once for the specular
+            // term (shading.h:154,192), shadow_samples rays each; a ray that reaches the light adds weight/samples.
+            const double inv_s = 1.0 / P.shadow_samples;
+            const D3 org = Pt + N * P.eps_shadow;
+            for (int pass = 0; pass < 2; ++pass) {
+                const D3 wt = (pass == 0) ? cmul(w, diff * ad_weight) * inv_s : cmul(w, sp) * inv_s;
+                for (int k = 0; k < P.shadow_samples; ++k) {
+                    D3 lp = ld3(L.pos);
+                    if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
+                    D3 d = lp - Pt;
+                    double dist = length(d);
+                    d = normalize(d);
+                    emit_ray(E.out, E.count, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth, kKindShadow);
+                }
+            }
+        }
+    }
+    accum_add(accum, q.pixel, cmul(w, ad * ad_weight + spec));
+
+    // ---- secondary rays
+    const int child_depth = q.depth - 1;
+    if (child_depth <= 0) return;  // children would return black without tracing (tracer.h:149)
+    if (has_refl) {  // tracer.h:176-219
+        int samples = P.glossy_samples;
+        if (q.depth < P.max_bounces) samples = 1;
+        double rough = 1.0 / sqrt(M.shininess);
+        D3 Vn = normalize(r.d);
+        D3 perfect = normalize(reflect(Vn, h.n));
+        D3 wr = w * refl_weight;
+        if (M.is_metal) wr = cmul(wr, ld3(M.diffuse));
+        D3 org = h.p + h.n * eps;
+        if (samples > 0) {
+            wr = wr * (1.0 / samples);
+            for (int k = 0; k < samples; ++k) {
+                D3 off = rng.in_unit_sphere() * rough;
+                D3 target = normalize(perfect + off);
+                if (dot(target, h.n) > 0)
+                    emit_ray(E.out, E.count, E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+            }
+        } else {
+            emit_ray(E.out, E.count, E.cap, E.overflow, org, perfect, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+        }
+    }
+    if (tir_mirror)  // tracer.h:258-264 (not tinted for metals)
+        emit_ray(E.out, E.count, E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time, 100000.0,
+                 rng.next(), q.pixel, child_depth, kKindRadiance);
+    if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
+        emit_ray(E.out, E.count, E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time, 100000.0,
+                 rng.next(), q.pixel, child_depth, kKindRadiance);
+}
+
+// ------------------------------------------------------------------------------------------ k_resolve
+__global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ accum, uint8_t* __restrict__ out, const int npix,
+                                                    const int spp, const int mode) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    D3 c = mk(accum[i * 3 + 0], accum[i * 3 + 1], accum[i * 3 + 2]);
+    D3 avg = tonemap(c * (1.0 / spp), mode);  // main.cpp:308-316
+    out[i * 3 + 0] = quantise(avg.x);
+    out[i * 3 + 1] = quantise(avg.y);
+    out[i * 3 + 2] = quantise(avg.z);
+}
+
+__global__ void k_add_counters(unsigned long long* c, unsigned long long rays, unsigned long long boxes, unsigned long long prims) {
+    if (threadIdx.x == 0) { c[0] += rays; c[1] += boxes; c[2] += prims; }
+}
+
+// ------------------------------------------------------------------------------------------ host driver
+constexpr int kSpheres = RT_FEAT_SPHERE;
+constexpr int kAnalytic = RT_FEAT_SPHERE | RT_FEAT_QUAD | RT_FEAT_CUBE;
+constexpr int kFull = kAnalytic | RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV;
+
+struct Driver {
+    const DScene& S;
+    const DParams& P;
+    WavefrontWorkspace& ws;
+    hipStream_t stream;
+    int variant;
+    int traverse_blocks;
+    unsigned long long rays_traced = 0;
+    hipError_t err = hipSuccess;
+
+    bool ok(hipError_t e) {
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        return err == hipSuccess;
+    }
+    RayRec* rays(int q) { return static_cast<RayRec*>(ws.queues[q]); }
+    HitRec* hits(int q) { return static_cast<HitRec*>(ws.hit_buffers[q]); }
+
+    int acquire() {
+        for (size_t i = 0; i < ws.queues.size(); ++i)
+            if (!ws.in_use[i]) { ws.in_use[i] = 1; return (int)i; }
+        void *q = nullptr, *h = nullptr;
+        if (!ok(hipMalloc(&q, ws.capacity * sizeof(RayRec)))) return -1;
+        if (!ok(hipMalloc(&h, ws.capacity * sizeof(HitRec)))) { (void)hipFree(q); return -1; }
+        ws.queues.push_back(q);
+        ws.hit_buffers.push_back(h);
+        ws.in_use.push_back(1);
+        return (int)ws.queues.size() - 1;
+    }
+    void release(int q) { ws.in_use[q] = 0; }
+
+    // worst-case number of rays one queued ray can emit at `level` (radiance rays there have depth max_depth - level)
+    size_t fanout(int level) const {
+        int depth = P.max_depth - level;
+        size_t refl = (depth < P.max_bounces) ? 1 : (size_t)std::max(P.glossy_samples, 1);
+        size_t shadow = P.shadows ? 2ull * (size_t)S.n_lights * (size_t)P.shadow_samples : 0ull;
+        return std::max<size_t>(1, refl + 1 + shadow);
+    }
+
+    template <int F> void launch_traverse(int q, unsigned n) {
+        hipLaunchKernelGGL(k_traverse<F>, dim3(traverse_blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, ws.counters + 0,
+                           ws.stats);
+    }
+    template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo) {
+        EmitCtx E{rays(qo), ws.counters + 1, ws.counters + 2, (unsigned)ws.capacity};
+        hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q) + start, hits(q) + start, n,
+                           E, ws.accum);
+    }
+
+    // Trace and shade the n rays of queue q (owned by this call, released when fully consumed), then their children.
+    void process(int q, unsigned n, int level) {
+        if (err != hipSuccess || n == 0) { release(q); return; }
+        if (!ok(hipMemsetAsync(ws.counters, 0, sizeof(unsigned), stream))) { release(q); return; }
+        if (variant == 0) launch_traverse<kSpheres>(q, n);
+        else if (variant == 1) launch_traverse<kAnalytic>(q, n);
+        else launch_traverse<kFull>(q, n);
+        rays_traced += n;
+        const size_t fo = fanout(level);
+        const unsigned batch = (unsigned)std::max<size_t>(1, std::min<size_t>(n, ws.capacity / fo));
+        for (unsigned start = 0; start < n && err == hipSuccess; start += batch) {
+            const unsigned m = std::min(batch, n - start);
+            const int qo = acquire();
+            if (qo < 0) break;
+            if (!ok(hipMemsetAsync(ws.counters + 1, 0, 2 * sizeof(unsigned), stream))) { release(qo); break; }
+            if (variant == 0) launch_shade<kSpheres>(q, start, m, qo);
+            else if (variant == 1) launch_shade<kAnalytic>(q, start, m, qo);
+            else launch_shade<kFull>(q, start, m, qo);
+            unsigned res[2] = {0, 0};
+            if (!ok(hipMemcpyAsync(res, ws.counters + 1, sizeof(res), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
+                release(qo);
+                break;
+            }
+            if (res[1]) { ok(hipErrorOutOfMemory); release(qo); break; }  // queue overflow: cannot happen with the batching above
+            if (start + m >= n) { release(q); q = -1; }                    // input fully consumed: its buffers may be reused below
+            process(qo, res[0], level + 1);
+        }
+        if (q >= 0) release(q);
+    }
+};
+
+}  // namespace
+
+void wavefront_workspace_free(WavefrontWorkspace& ws) {
+    for (void* p : ws.queues) (void)hipFree(p);
+    for (void* p : ws.hit_buffers) (void)hipFree(p);
+    if (ws.accum) (void)hipFree(ws.accum);
+    if (ws.counters) (void)hipFree(ws.counters);
+    if (ws.stats) (void)hipFree(ws.stats);
+    ws = WavefrontWorkspace();
+}
+
+hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
+                                   hipStream_t stream, WavefrontWorkspace& ws) {
+    const size_t npix = (size_t)params.part_rows * params.width;
+    if (npix == 0) return hipSuccess;
+    hipError_t e;
+    if (ws.capacity == 0) {
+        const char* env = getenv("RT_QUEUE_RAYS");
+        size_t cap = env ? strtoull(env, nullptr, 10) : 0;
+        ws.capacity = cap >= 4096 ? cap : (size_t(1) << 24);
+        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), 16 * sizeof(unsigned))) != hipSuccess) return e;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), 4 * sizeof(unsigned long long))) != hipSuccess) return e;
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        ws.compute_units = cus;
+    }
+    if (ws.accum_pixels < npix) {
+        if (ws.accum) (void)hipFree(ws.accum);
+        ws.accum = nullptr;
+        ws.accum_pixels = 0;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.accum), npix * 3 * sizeof(double))) != hipSuccess) return e;
+        ws.accum_pixels = npix;
+    }
+    if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+
+    Driver D{scene, params, ws, stream, 0, 0};
+    const int f = scene.features;
+    D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
+    // persistent traversal grid: every CU gets RT_TRAVERSE_WAVES waves per SIMD (LDS: 24 KB per 256-thread block)
+    D.traverse_blocks = ws.compute_units * RT_TRAVERSE_WAVES;
+
+    // Primary rays are generated in chunks of whole 8-row bands x a batch of samples, sized so that the first
+    // level's children always fit one queue.
+    const size_t fo0 = D.fanout(0);
+    const size_t max_primary = std::max<size_t>(64, ws.capacity / fo0);
+    const int W = params.width;
+    int ns = (int)std::min<size_t>((size_t)params.spp, std::max<size_t>(1, max_primary / ((size_t)W * 8)));
+    int rows_per_chunk = (int)std::min<size_t>((size_t)params.part_rows, std::max<size_t>(8, (max_primary / ((size_t)W * ns)) / 8 * 8));
+    if ((size_t)rows_per_chunk * W * ns > ws.capacity) return hipErrorInvalidValue;  // frame wider than the queue: raise RT_QUEUE_RAYS
+    for (int row0 = 0; row0 < params.part_rows && D.err == hipSuccess; row0 += rows_per_chunk) {
+        const int rows = std::min(rows_per_chunk, params.part_rows - row0);
+        for (int s0 = 0; s0 < params.spp && D.err == hipSuccess; s0 += ns) {
+            Chunk ck{row0, rows, s0, std::min(ns, params.spp - s0)};
+            const long long n = (long long)rows * W * ck.ns;
+            const int q = D.acquire();
+            if (q < 0) break;
+            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n);
+            D.process(q, (unsigned)n, 0);
+        }
+    }
+    if (D.err != hipSuccess) return D.err;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
+                       params.spp, params.tonemap);
+    if (d_counters) {  // rays are counted on the host (every traversed queue entry is one closest-hit query)
+        ws.host_counts[0] = D.rays_traced;
+        if ((e = hipMemcpyAsync(ws.host_counts + 1, ws.stats + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, ws.host_counts[0], ws.host_counts[1], ws.host_counts[2]);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rt

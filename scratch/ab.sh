@@ -1,0 +1,6 @@
+#!/bin/bash
+# A/B of library builds: scratch/ab.sh <lib suffixes...>
+for v in "$@"; do
+  echo "== $v"
+  RT_MI355X_LIB=$GRAFT_REPO_ROOT/raytracer_amd/librt_mi355x_$v.so timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['kernel_ms'])" || exit 1
+done

@@ -17,9 +17,14 @@ TOL = 1                 # 8-bit levels, from north_star
 MAX_OFF_FRACTION = 0.01  # at most 1 % of the channels may differ at all (by 1)
 
 
+SCHEDULES = {"wavefront": rt.RT_SCHEDULE_WAVEFRONT, "megakernel": rt.RT_SCHEDULE_MEGAKERNEL}
+
+
+@pytest.mark.parametrize("schedule", sorted(SCHEDULES))
 @pytest.mark.parametrize("name", helpers.CASES)
-def test_hip_matches_reference_golden(gpu, name):
+def test_hip_matches_reference_golden(gpu, name, schedule):
     scene_file, params, golden = helpers.load_case(name)
+    params.schedule = SCHEDULES[schedule]
     scene = rt.Scene(scene_file)
     img, st = scene.render(params, stats=True)
     scene.close()
@@ -29,11 +34,13 @@ def test_hip_matches_reference_golden(gpu, name):
     assert st.rays > 0
 
 
+@pytest.mark.parametrize("schedule", sorted(SCHEDULES))
 @pytest.mark.parametrize("name", ["c1_shadows_fresnel", "bvh_100_shaded", "own_glass_env", "own_complex", "gal_shapes"])
-def test_ray_counts_match_oracle(gpu, name):
+def test_ray_counts_match_oracle(gpu, name, schedule):
     """Rays == closest-hit queries == reference world.intersect calls; must match the oracle exactly
     when the images match (same tree of rays)."""
     scene_file, params, golden = helpers.load_case(name)
+    params.schedule = SCHEDULES[schedule]
     ref_img, counters = oracle_py.render(scene_file, params, counters=True)
     scene = rt.Scene(scene_file)
     img, st = scene.render(params, stats=True)
