@@ -474,19 +474,43 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
 }
 
 // aabb.cpp:4-38, with 1/d hoisted out (same value).  Returns the entry distance in `entry`.
+// Branch-free: the reference leaves the axis loop at the first axis with tmax <= tmin; tmin only grows and tmax only
+// shrinks, so "some axis failed" is the same predicate, and evaluating all three axes lets every load of a node be
+// issued before the first use (one memory round trip per node instead of one per axis).
 __device__ __forceinline__ bool box_test(const double* lo, const double* hi, const double* o, const double* inv, double tmin,
                                          double tmax, double& entry) {
+    bool ok = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         double t0 = (lo[a] - o[a]) * inv[a];
         double t1 = (hi[a] - o[a]) * inv[a];
-        if (inv[a] < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) return false;
+        const bool neg = inv[a] < 0.0;
+        const double tn = neg ? t1 : t0, tf = neg ? t0 : t1;
+        tmin = tn > tmin ? tn : tmin;
+        tmax = tf < tmax ? tf : tmax;
+        ok = ok && !(tmax <= tmin);
     }
     entry = tmin;
-    return true;
+    return ok;
+}
+
+// One interior node pulled into registers with eight 16-byte loads issued back to back.
+typedef double rt_d2 __attribute__((ext_vector_type(2)));
+struct NodeRegs {
+    double lo[2][3], hi[2][3];
+    int child[2];
+};
+__device__ __forceinline__ NodeRegs load_node(const DNode* n) {
+    const rt_d2* p = reinterpret_cast<const rt_d2*>(n);
+    const rt_d2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6];
+    NodeRegs r;
+    r.lo[0][0] = a0.x; r.lo[0][1] = a0.y; r.lo[0][2] = a1.x;
+    r.lo[1][0] = a1.y; r.lo[1][1] = a2.x; r.lo[1][2] = a2.y;
+    r.hi[0][0] = a3.x; r.hi[0][1] = a3.y; r.hi[0][2] = a4.x;
+    r.hi[1][0] = a4.y; r.hi[1][1] = a5.x; r.hi[1][2] = a5.y;
+    r.child[0] = __double2loint(a6.x);
+    r.child[1] = __double2hiint(a6.x);
+    return r;
 }
 
 // Closest hit == `world.intersect(r, tmin, tmax, rec)` (hittable_list.cpp:8-33 over bvh.cpp:101-114).
@@ -520,12 +544,12 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
     // expensive FP64 primitive tests below run with many lanes active instead of once per node step.
     while (cur != kDone) {
         while (static_cast<unsigned>(cur) < static_cast<unsigned>(kDone)) {  // 0 <= cur < kDone: interior node
-            const DNode* n = &S.nodes[cur];
+            const NodeRegs n = load_node(&S.nodes[cur]);
             if (P.count_tests) C.nodes += 2;
             double e0, e1;
-            bool h0 = box_test(n->lo[0], n->hi[0], o, inv, tmin, best.t, e0);
-            bool h1 = box_test(n->lo[1], n->hi[1], o, inv, tmin, best.t, e1);
-            int c0 = n->child[0], c1 = n->child[1];
+            bool h0 = box_test(n.lo[0], n.hi[0], o, inv, tmin, best.t, e0);
+            bool h1 = box_test(n.lo[1], n.hi[1], o, inv, tmin, best.t, e1);
+            int c0 = n.child[0], c1 = n.child[1];
             if (h0 && h1) {
                 bool left_first = !(e1 < e0);
                 stack.at(sp++) = left_first ? c1 : c0;

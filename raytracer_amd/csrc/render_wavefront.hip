@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 
 // ------------------------------------------------------------------------------------------ k_traverse
 #ifndef RT_TRAVERSE_WAVES
-#define RT_TRAVERSE_WAVES 6       // waves per SIMD asked of the register allocator
+#define RT_TRAVERSE_WAVES 4       // waves per SIMD asked of the register allocator
 #endif
 #ifndef RT_NODE_VOTE
 #define RT_NODE_VOTE 24           // run an interior-node step while at least this many lanes want one
@@ -207,12 +207,12 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
         const unsigned long long mn = __ballot(is_node), ml = __ballot(is_leaf);
         if (mn != 0ull && (__popcll(mn) >= RT_NODE_VOTE || ml == 0ull)) {
             if (is_node) {
-                const DNode* nd = &S.nodes[cur];
+                const NodeRegs nd = load_node(&S.nodes[cur]);
                 if (P.count_tests) C.nodes += 2;
                 double e0, e1;
-                const bool h0 = box_test(nd->lo[0], nd->hi[0], o, inv, tmin, best.t, e0);
-                const bool h1 = box_test(nd->lo[1], nd->hi[1], o, inv, tmin, best.t, e1);
-                const int c0 = nd->child[0], c1 = nd->child[1];
+                const bool h0 = box_test(nd.lo[0], nd.hi[0], o, inv, tmin, best.t, e0);
+                const bool h1 = box_test(nd.lo[1], nd.hi[1], o, inv, tmin, best.t, e1);
+                const int c0 = nd.child[0], c1 = nd.child[1];
                 if (h0 && h1) {
                     const bool left_first = !(e1 < e0);
                     stack.at(sp++) = left_first ? c1 : c0;
