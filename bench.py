@@ -32,7 +32,7 @@ import raytracer_amd as rt  # noqa: E402
 from raytracer_amd import workloads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NODE_BYTES_PER_BOX = 64   # one 128-byte DNode carries two child boxes (device_types.h)
+NODE_BYTES_PER_BOX = 32   # one 64-byte DNode32 carries two FP32 child boxes (device_types.h)
 SPHERE_BYTES = 16 + 144   # DPrim header + DXform (device_types.h)
 RAY_STATE_BYTES = 16      # amortised framebuffer + ray state traffic per ray
 
@@ -189,7 +189,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_render", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_ray": "64*box_tests + 160*sphere_tests + 16"},
+                         "bytes_per_ray": "32*box_tests + 160*sphere_tests + 16"},
         }
         if world == 1 and not args.no_cpu_baseline:
             p1 = params.copy()

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -267,8 +268,11 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         for (void* p : sc->allocations) (void)hipFree(p);
         return code;
     };
-    DNode* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
-    if ((rc = upload(sc->bvh.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
+    DNode32* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
+    double max_origin = 0.0;
+    for (int a = 0; a < 3; ++a) max_origin = std::max(max_origin, std::fabs(desc->camera.location[a]));
+    Bvh32 b32 = to_node32(sc->bvh, max_origin);
+    if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
     if ((rc = upload(h.prims, &d_prims))) return cleanup_fail(rc); track(d_prims);
     if ((rc = upload(h.file_order, &d_forder))) return cleanup_fail(rc); track(d_forder);
     if ((rc = upload(h.xforms, &d_x))) return cleanup_fail(rc); track(d_x);
@@ -304,8 +308,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     d.n_lights = desc->n_lights;
     d.root_ref = sc->bvh.root_ref;
     d.features = h.features;
-    store(d.root_lo, sc->bvh.root_box.lo);
-    store(d.root_hi, sc->bvh.root_box.hi);
+    for (int a = 0; a < 3; ++a) { d.root_lo[a] = b32.root_lo[a]; d.root_hi[a] = b32.root_hi[a]; }
     d.shutter_time = desc->shutter_time;
     d.cam = h.cam;
     sc->on_device = true;

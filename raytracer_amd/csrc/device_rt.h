@@ -473,43 +473,61 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
     }
 }
 
-// aabb.cpp:4-38, with 1/d hoisted out (same value).  Returns the entry distance in `entry`.
-// Branch-free: the reference leaves the axis loop at the first axis with tmax <= tmin; tmin only grows and tmax only
-// shrinks, so "some axis failed" is the same predicate, and evaluating all three axes lets every load of a node be
-// issued before the first use (one memory round trip per node instead of one per axis).
-__device__ __forceinline__ bool box_test(const double* lo, const double* hi, const double* o, const double* inv, double tmin,
-                                         double tmax, double& entry) {
-    bool ok = true;
+// Slab test of aabb.cpp:4-38 in FP32 on the widened boxes of DNode32.  It only has to be CONSERVATIVE: whenever the
+// reference's FP64 test (running tmin/tmax over the three axes, reject on tmax <= tmin) accepts, this one accepts.
+//   * the box was moved outward on the host by more than the FP32 rounding of the ray origin;
+//   * every FP32 operation below has relative error <= 2^-24, so entry distances are lowered and exit distances
+//     raised by 2^-21 relative before they are compared;
+//   * tmin is rounded down and tmax up when converted;
+//   * a NaN (0 x inf, origin exactly on a slab plane of an axis-parallel ray) is ignored by fmaxf/fminf, which can
+//     only widen the interval.
+// The reference leaves its axis loop at the first failing axis; since tmin only grows and tmax only shrinks that is
+// the same predicate as "final exit <= final entry", evaluated here without branches so that the four loads of a
+// node are issued together (one memory round trip per node).
+struct RayF {
+    float o[3], inv[3];
+};
+__device__ __forceinline__ RayF make_rayf(const Ray& r) {
+    RayF f;
+    f.o[0] = (float)r.o.x; f.o[1] = (float)r.o.y; f.o[2] = (float)r.o.z;
+    f.inv[0] = (float)(1.0 / r.d.x); f.inv[1] = (float)(1.0 / r.d.y); f.inv[2] = (float)(1.0 / r.d.z);
+    return f;
+}
+__device__ __forceinline__ bool box_test32(const float* lo, const float* hi, const RayF& f, float tmin, float tmax, float& entry) {
+    constexpr float kSlack = 4.76837158e-7f;  // 2^-21
+    float tn = -INFINITY, tf = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        double t0 = (lo[a] - o[a]) * inv[a];
-        double t1 = (hi[a] - o[a]) * inv[a];
-        const bool neg = inv[a] < 0.0;
-        const double tn = neg ? t1 : t0, tf = neg ? t0 : t1;
-        tmin = tn > tmin ? tn : tmin;
-        tmax = tf < tmax ? tf : tmax;
-        ok = ok && !(tmax <= tmin);
+        const bool neg = f.inv[a] < 0.0f;
+        const float t0 = ((neg ? hi[a] : lo[a]) - f.o[a]) * f.inv[a];
+        const float t1 = ((neg ? lo[a] : hi[a]) - f.o[a]) * f.inv[a];
+        tn = fmaxf(tn, t0);
+        tf = fminf(tf, t1);
     }
-    entry = tmin;
-    return ok;
+    tn = tn - fabsf(tn) * kSlack;
+    tf = tf + fabsf(tf) * kSlack;
+    tn = fmaxf(tn, tmin);   // a NaN interval end falls back to the ray's own range
+    tf = fminf(tf, tmax);
+    entry = tn;
+    return tf >= tn;
 }
 
-// One interior node pulled into registers with eight 16-byte loads issued back to back.
-typedef double rt_d2 __attribute__((ext_vector_type(2)));
+// One interior node pulled into registers with four 16-byte loads issued back to back.
+typedef float rt_f4 __attribute__((ext_vector_type(4)));
 struct NodeRegs {
-    double lo[2][3], hi[2][3];
+    float lo[2][3], hi[2][3];
     int child[2];
 };
-__device__ __forceinline__ NodeRegs load_node(const DNode* n) {
-    const rt_d2* p = reinterpret_cast<const rt_d2*>(n);
-    const rt_d2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6];
+__device__ __forceinline__ NodeRegs load_node(const DNode32* n) {
+    const rt_f4* p = reinterpret_cast<const rt_f4*>(n);
+    const rt_f4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
     NodeRegs r;
-    r.lo[0][0] = a0.x; r.lo[0][1] = a0.y; r.lo[0][2] = a1.x;
-    r.lo[1][0] = a1.y; r.lo[1][1] = a2.x; r.lo[1][2] = a2.y;
-    r.hi[0][0] = a3.x; r.hi[0][1] = a3.y; r.hi[0][2] = a4.x;
-    r.hi[1][0] = a4.y; r.hi[1][1] = a5.x; r.hi[1][2] = a5.y;
-    r.child[0] = __double2loint(a6.x);
-    r.child[1] = __double2hiint(a6.x);
+    r.lo[0][0] = a0.x; r.lo[0][1] = a0.y; r.lo[0][2] = a0.z;
+    r.lo[1][0] = a0.w; r.lo[1][1] = a1.x; r.lo[1][2] = a1.y;
+    r.hi[0][0] = a1.z; r.hi[0][1] = a1.w; r.hi[0][2] = a2.x;
+    r.hi[1][0] = a2.y; r.hi[1][1] = a2.z; r.hi[1][2] = a2.w;
+    r.child[0] = __float_as_int(a3.x);
+    r.child[1] = __float_as_int(a3.y);
     return r;
 }
 
@@ -531,11 +549,11 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
         for (int i = 0; i < S.n_prims; ++i) test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
         return best.prim >= 0;
     }
-    const double o[3] = {r.o.x, r.o.y, r.o.z};
-    const double inv[3] = {1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z};
-    double e;
+    const RayF rf = make_rayf(r);
+    const float tmin32 = __double2float_rd(tmin);
+    float e;
     if (P.count_tests) C.nodes++;
-    if (!box_test(S.root_lo, S.root_hi, o, inv, tmin, tmax, e)) return false;
+    if (!box_test32(S.root_lo, S.root_hi, rf, tmin32, __double2float_ru(tmax), e)) return false;
     int sp = 0;
     int cur = S.root_ref;
     constexpr int kDone = 0x7fffffff;
@@ -546,9 +564,10 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
         while (static_cast<unsigned>(cur) < static_cast<unsigned>(kDone)) {  // 0 <= cur < kDone: interior node
             const NodeRegs n = load_node(&S.nodes[cur]);
             if (P.count_tests) C.nodes += 2;
-            double e0, e1;
-            bool h0 = box_test(n.lo[0], n.hi[0], o, inv, tmin, best.t, e0);
-            bool h1 = box_test(n.lo[1], n.hi[1], o, inv, tmin, best.t, e1);
+            float e0, e1;
+            const float tmax32 = __double2float_ru(best.t);
+            bool h0 = box_test32(n.lo[0], n.hi[0], rf, tmin32, tmax32, e0);
+            bool h1 = box_test32(n.lo[1], n.hi[1], rf, tmin32, tmax32, e1);
             int c0 = n.child[0], c1 = n.child[1];
             if (h0 && h1) {
                 bool left_first = !(e1 < e0);

@@ -14,7 +14,7 @@
 
 namespace rt {
 
-constexpr int kNodeBytes = 128;       // one DNode
+constexpr int kNodeBytes = 64;        // one DNode32 (what the device traverses)
 constexpr int kTravStackDepth = 24;   // per-lane traversal stack entries (LDS); host refuses deeper trees
 constexpr int kRayStackDepth = 32;    // per-lane pending-ray stack entries (scratch)
 constexpr int kShadowMaxSegments = 256;
@@ -33,7 +33,19 @@ struct alignas(128) DNode {
     int32_t child[2];
     int32_t pad[6];
 };
-static_assert(sizeof(DNode) == kNodeBytes, "DNode must be 128 bytes");
+static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
+
+// What the device actually traverses: the same node with its two child boxes in FP32, widened outward on the host
+// (host_bvh.cpp: to_node32) so that the FP32 slab test of device_rt.h accepts every ray the reference's FP64 test
+// (aabb.cpp:4-38) accepts.  Boxes only cull; every hit/miss decision is made by the FP64 primitive tests, so a
+// conservative (superset) traversal yields the same closest hit.  64 bytes, 64-byte aligned: four 16-byte loads.
+struct alignas(64) DNode32 {
+    float lo[2][3];   // [child][axis]
+    float hi[2][3];
+    int32_t child[2];
+    int32_t pad[2];
+};
+static_assert(sizeof(DNode32) == kNodeBytes, "DNode32 must be 64 bytes");
 
 // Per-primitive header, in BVH depth-first (leaf) order.
 struct alignas(16) DPrim {
@@ -100,7 +112,7 @@ struct DCamera {
 
 // Everything the kernel needs to find the scene; passed by value as a kernel argument.
 struct DScene {
-    const DNode* nodes;
+    const DNode32* nodes;
     const DPrim* prims;           // depth-first order
     const int32_t* file_order;    // file_order[i] = prim index of the i-th shape in the scene file
     const DXform* xforms;
@@ -113,7 +125,8 @@ struct DScene {
     int32_t n_prims, n_nodes, n_lights;
     int32_t root_ref;             // reference to the root (node 0 or a leaf)
     int32_t features;             // RT_FEAT_* bits: which code paths this scene can reach
-    double root_lo[3], root_hi[3];
+    float root_lo[3], root_hi[3];   // widened like the node boxes
+    int32_t pad_root[2];
     double shutter_time;
     DCamera cam;
 };

@@ -1,6 +1,7 @@
 #include "host_bvh.h"
 
 #include <algorithm>
+#include <cmath>
 #include <limits>
 #include <numeric>
 
@@ -121,6 +122,50 @@ struct Builder {
 };
 
 }  // namespace
+
+static float round_down(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+static float round_up(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+Bvh32 to_node32(const HostBvh& bvh, double max_abs_origin) {
+    Bvh32 out;
+    double m = max_abs_origin;
+    auto grow_abs = [&](const double* p) { for (int a = 0; a < 3; ++a) if (std::isfinite(p[a])) m = std::max(m, std::fabs(p[a])); };
+    double rl[3], rh[3];
+    store(rl, bvh.root_box.lo);
+    store(rh, bvh.root_box.hi);
+    grow_abs(rl);
+    grow_abs(rh);
+    // ray origins: the camera, and surface points inside the root box moved by at most ~1e-3 (tracer.h:201,
+    // shading.h:68,93).  2^-22 * m = 4x the FP32 rounding of such an origin.
+    out.pad = (m + 0.01) * std::ldexp(1.0, -22);
+    const double pad = out.pad;
+    out.nodes.resize(bvh.nodes.size());
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+        const DNode& n = bvh.nodes[i];
+        DNode32& o = out.nodes[i];
+        for (int c = 0; c < 2; ++c)
+            for (int a = 0; a < 3; ++a) {
+                o.lo[c][a] = round_down(n.lo[c][a] - pad);
+                o.hi[c][a] = round_up(n.hi[c][a] + pad);
+            }
+        o.child[0] = n.child[0];
+        o.child[1] = n.child[1];
+        o.pad[0] = o.pad[1] = 0;
+    }
+    for (int a = 0; a < 3; ++a) {
+        out.root_lo[a] = round_down(rl[a] - pad);
+        out.root_hi[a] = round_up(rh[a] + pad);
+    }
+    return out;
+}
 
 HostBvh build_bvh(const RtSceneDesc& desc) {
     std::vector<Box> boxes(desc.n_shapes);

@@ -21,6 +21,16 @@ struct HostBvh {
 // complex_sphere.cpp:21-27, complex_cube.cpp:25-31, complex_plane.cpp:24-75).
 Box shape_bounds(const RtShape& s, double shutter_time);
 
+// FP32 image of the hierarchy for the device.  Every box is moved outward by an absolute pad that covers the rounding
+// of a ray origin to FP32 (|o| <= max_abs_coord, so |fl32(o) - o| <= 2^-24 max_abs_coord) and then rounded outward
+// to FP32; the relative rounding of the slab arithmetic itself is covered on the device (device_rt.h: box_test32).
+struct Bvh32 {
+    std::vector<DNode32> nodes;
+    float root_lo[3], root_hi[3];
+    double pad = 0;
+};
+Bvh32 to_node32(const HostBvh& bvh, double max_abs_origin);
+
 // n_shapes == 0 yields an empty hierarchy (root_ref is a leaf of zero primitives; callers must check).
 HostBvh build_bvh(const RtSceneDesc& desc);
 

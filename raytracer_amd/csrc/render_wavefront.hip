@@ -150,8 +150,9 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
     bool active = false, exhausted = false;
     unsigned my = 0;
     Ray r{mk(0, 0, 0), mk(0, 0, 1), 0.0};
-    double o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    RayF rf{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     double tmin = 0.0;
+    float tmin32 = 0.f;
     Cand best{0.0, -1, 0, 0.0, 0.0};
     int best_order = 0, sp = 0, cur = kDone;
     bool best_incl = false;
@@ -184,12 +185,12 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
                     cur = kDone;
                     active = true;
                     if (S.n_prims > 0) {
-                        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
-                        inv[0] = 1.0 / r.d.x; inv[1] = 1.0 / r.d.y; inv[2] = 1.0 / r.d.z;
                         if (P.use_bvh) {
-                            double e;
+                            rf = make_rayf(r);
+                            tmin32 = __double2float_rd(tmin);
+                            float e;
                             if (P.count_tests) C.nodes++;
-                            if (box_test(S.root_lo, S.root_hi, o, inv, tmin, tmax, e)) cur = S.root_ref;
+                            if (box_test32(S.root_lo, S.root_hi, rf, tmin32, __double2float_ru(tmax), e)) cur = S.root_ref;
                         } else {  // --no-bvh: the list in scene-file order (hittable_list.cpp:8-33)
                             for (int i = 0; i < S.n_prims; ++i) test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
                         }
@@ -209,9 +210,10 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
             if (is_node) {
                 const NodeRegs nd = load_node(&S.nodes[cur]);
                 if (P.count_tests) C.nodes += 2;
-                double e0, e1;
-                const bool h0 = box_test(nd.lo[0], nd.hi[0], o, inv, tmin, best.t, e0);
-                const bool h1 = box_test(nd.lo[1], nd.hi[1], o, inv, tmin, best.t, e1);
+                float e0, e1;
+                const float tmax32 = __double2float_ru(best.t);
+                const bool h0 = box_test32(nd.lo[0], nd.hi[0], rf, tmin32, tmax32, e0);
+                const bool h1 = box_test32(nd.lo[1], nd.hi[1], rf, tmin32, tmax32, e1);
                 const int c0 = nd.child[0], c1 = nd.child[1];
                 if (h0 && h1) {
                     const bool left_first = !(e1 < e0);

@@ -132,7 +132,7 @@ def test_bvh_build_matches_reference_structure():
     scene, params, _ = helpers.load_case("bvh_100_normals")
     info, order = rt.bvh_build_host(scene)
     assert info.n_prims == 100 and sorted(order.tolist()) == list(range(100))
-    assert info.node_bytes == 128
+    assert info.node_bytes == 64
     # median split: leaves hold 1-2 shapes, interior nodes = leaves - 1, depth = ceil(log2(100/2)) or so
     assert 49 <= info.n_nodes <= 99 and 5 <= info.max_depth <= 7
     scene1, _, _ = helpers.load_case("bvh_1_normals")
