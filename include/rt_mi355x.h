@@ -176,7 +176,8 @@ typedef struct RtStats {
     uint64_t rays;            /* closest-hit queries == reference world.intersect calls (tracer.h:156, shading.h:45) */
     uint64_t nodes_visited;   /* BVH node boxes tested   (filled only when collect_counters != 0) */
     uint64_t prims_tested;    /* primitive intersection tests (same)                              */
-    double kernel_ms;         /* device time of the render kernel (hipEvent), 0 if not measured    */
+    double kernel_ms;         /* device time of the whole render (all kernels, hipEvent)            */
+    double traverse_ms;       /* of which: the BVH traversal kernel launches (wavefront schedule)   */
     double total_ms;          /* wall time of the call incl. copies                                */
 } RtStats;
 
@@ -225,8 +226,8 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
 
 /* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t, NULL = the library's
  * stream): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice
- * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to 4 uint64 (rays, nodes, prims,
- * reserved) that the kernel adds into; collect_counters!=0 additionally counts node/primitive tests. */
+ * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to 4 uint64 (rays, box tests,
+ * primitive tests, nanoseconds spent in the traversal kernel) that the kernel adds into; collect_counters!=0 additionally counts node/primitive tests. */
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);
 

@@ -450,6 +450,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
         stats->nodes_visited = counters[1];
         stats->prims_tested = counters[2];
         stats->kernel_ms = ms;
+        stats->traverse_ms = static_cast<double>(counters[3]) * 1e-6;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RT_OK;

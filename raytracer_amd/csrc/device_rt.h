@@ -479,33 +479,31 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
 //   * every FP32 operation below has relative error <= 2^-24, so entry distances are lowered and exit distances
 //     raised by 2^-21 relative before they are compared;
 //   * tmin is rounded down and tmax up when converted;
-//   * a NaN (0 x inf, origin exactly on a slab plane of an axis-parallel ray) is ignored by fmaxf/fminf, which can
-//     only widen the interval.
+//   * a NaN (inf - inf on an axis-parallel ray) is ignored by fmaxf/fminf, which can only widen the interval.
 // The reference leaves its axis loop at the first failing axis; since tmin only grows and tmax only shrinks that is
 // the same predicate as "final exit <= final entry", evaluated here without branches so that the four loads of a
 // node are issued together (one memory round trip per node).
 struct RayF {
-    float o[3], inv[3];
+    float inv[3], oi[3];   // 1/d and o * (1/d), per axis
 };
 __device__ __forceinline__ RayF make_rayf(const Ray& r) {
     RayF f;
-    f.o[0] = (float)r.o.x; f.o[1] = (float)r.o.y; f.o[2] = (float)r.o.z;
     f.inv[0] = (float)(1.0 / r.d.x); f.inv[1] = (float)(1.0 / r.d.y); f.inv[2] = (float)(1.0 / r.d.z);
+    f.oi[0] = (float)r.o.x * f.inv[0]; f.oi[1] = (float)r.o.y * f.inv[1]; f.oi[2] = (float)r.o.z * f.inv[2];
     return f;
 }
+// t = B * inv - o * inv with one FMA per plane; the extra rounding of o*inv is of the size of the origin's own FP32
+// rounding, which the host pad covers four times over.  min/max order the two planes of an axis (no sign select).
+// For an exactly axis-parallel ray (inv = +-inf) both products are NaN and the axis simply does not constrain.
 __device__ __forceinline__ bool box_test32(const float* lo, const float* hi, const RayF& f, float tmin, float tmax, float& entry) {
     constexpr float kSlack = 4.76837158e-7f;  // 2^-21
-    float tn = -INFINITY, tf = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const bool neg = f.inv[a] < 0.0f;
-        const float t0 = ((neg ? hi[a] : lo[a]) - f.o[a]) * f.inv[a];
-        const float t1 = ((neg ? lo[a] : hi[a]) - f.o[a]) * f.inv[a];
-        tn = fmaxf(tn, t0);
-        tf = fminf(tf, t1);
-    }
-    tn = tn - fabsf(tn) * kSlack;
-    tf = tf + fabsf(tf) * kSlack;
+    const float ax = fmaf(lo[0], f.inv[0], -f.oi[0]), bx = fmaf(hi[0], f.inv[0], -f.oi[0]);
+    const float ay = fmaf(lo[1], f.inv[1], -f.oi[1]), by = fmaf(hi[1], f.inv[1], -f.oi[1]);
+    const float az = fmaf(lo[2], f.inv[2], -f.oi[2]), bz = fmaf(hi[2], f.inv[2], -f.oi[2]);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    tn = fmaf(-fabsf(tn), kSlack, tn);
+    tf = fmaf(fabsf(tf), kSlack, tf);
     tn = fmaxf(tn, tmin);   // a NaN interval end falls back to the ray's own range
     tf = fminf(tf, tmax);
     entry = tn;

@@ -27,6 +27,10 @@ struct WavefrontWorkspace {
     unsigned* counters = nullptr;        // [0] next ray to fetch, [1] rays emitted, [2] overflow flag
     unsigned long long* stats = nullptr; // [1] box tests, [2] primitive tests
     unsigned long long host_counts[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> events;      // start/stop pairs around the k_traverse launches of the current frame
+    size_t events_used = 0;
+    double last_traverse_ms = 0.0;       // summed k_traverse device time of the last frame whose counters were read
+    unsigned last_traverse_launches = 0;
     int compute_units = 256;
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);

@@ -448,8 +448,9 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ a
     out[i * 3 + 2] = quantise(avg.z);
 }
 
-__global__ void k_add_counters(unsigned long long* c, unsigned long long rays, unsigned long long boxes, unsigned long long prims) {
-    if (threadIdx.x == 0) { c[0] += rays; c[1] += boxes; c[2] += prims; }
+__global__ void k_add_counters(unsigned long long* c, unsigned long long rays, unsigned long long boxes, unsigned long long prims,
+                               unsigned long long traverse_ns) {
+    if (threadIdx.x == 0) { c[0] += rays; c[1] += boxes; c[2] += prims; c[3] += traverse_ns; }
 }
 
 // ------------------------------------------------------------------------------------------ host driver
@@ -495,7 +496,21 @@ struct Driver {
         return std::max<size_t>(1, refl + 1 + shadow);
     }
 
+    hipEvent_t next_event() {
+        if (ws.events_used == ws.events.size()) {
+            hipEvent_t e = nullptr;
+            if (!ok(hipEventCreate(&e))) return nullptr;
+            ws.events.push_back(e);
+        }
+        return ws.events[ws.events_used++];
+    }
     template <int F> void launch_traverse(int q, unsigned n) {
+        hipEvent_t e0 = next_event(), e1 = next_event();
+        if (e0) (void)hipEventRecord(e0, stream);
+        launch_traverse_kernel<F>(q, n);
+        if (e1) (void)hipEventRecord(e1, stream);
+    }
+    template <int F> void launch_traverse_kernel(int q, unsigned n) {
         hipLaunchKernelGGL(k_traverse<F>, dim3(traverse_blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, ws.counters + 0,
                            ws.stats);
     }
@@ -541,6 +556,7 @@ struct Driver {
 void wavefront_workspace_free(WavefrontWorkspace& ws) {
     for (void* p : ws.queues) (void)hipFree(p);
     for (void* p : ws.hit_buffers) (void)hipFree(p);
+    for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
     if (ws.accum) (void)hipFree(ws.accum);
     if (ws.counters) (void)hipFree(ws.counters);
     if (ws.stats) (void)hipFree(ws.stats);
@@ -573,6 +589,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
 
+    ws.events_used = 0;
     Driver D{scene, params, ws, stream, 0, 0};
     const int f = scene.features;
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
@@ -605,7 +622,15 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         ws.host_counts[0] = D.rays_traced;
         if ((e = hipMemcpyAsync(ws.host_counts + 1, ws.stats + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, ws.host_counts[0], ws.host_counts[1], ws.host_counts[2]);
+        double ms = 0.0;
+        for (size_t i = 0; i + 1 < ws.events_used; i += 2) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ws.events[i], ws.events[i + 1]) == hipSuccess) ms += t;
+        }
+        ws.last_traverse_ms = ms;
+        ws.last_traverse_launches = (unsigned)(ws.events_used / 2);
+        hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, ws.host_counts[0], ws.host_counts[1], ws.host_counts[2],
+                           (unsigned long long)(ms * 1e6));
     }
     return hipGetLastError();
 }
