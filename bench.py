@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 import raytracer_amd as rt  # noqa: E402
 from raytracer_amd import workloads  # noqa: E402
+from raytracer_amd.distributed import FrameGather  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NODE_BYTES_PER_BOX = 32   # one 64-byte DNode32 carries two FP32 child boxes (device_types.h)
@@ -90,24 +91,9 @@ def main():
     params.tile_rows, params.part_index, params.part_count = args.tile_rows, rank, world
     scene = rt.Scene(scene_desc)  # BVH build + upload: outside the timed region (scene resident in HBM)
     W, H = args.width, args.height
-    my_rows = rt.part_rows(H, args.tile_rows, rank, world)
-    max_rows = max(rt.part_rows(H, args.tile_rows, k, world) for k in range(world))
-    slice_t = torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)
+    fg = FrameGather(W, H, args.tile_rows, dev)   # slice buffer, gather buffers and de-interleave index (rank 0)
+    slice_t = fg.slice
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
-    gathered = [torch.empty_like(slice_t) for _ in range(world)] if (world > 1 and rank == 0) else None
-    frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-    # frame row -> (part, local row) gather index for the de-interleave on rank 0
-    if rank == 0 and world > 1:
-        src = np.empty(H, dtype=np.int64)
-        n_tiles = (H + args.tile_rows - 1) // args.tile_rows
-        for k in range(world):
-            lr = 0
-            for t in range(k, n_tiles, world):
-                y0 = t * args.tile_rows
-                rows = min(args.tile_rows, H - y0)
-                src[y0:y0 + rows] = k * max_rows + lr + np.arange(rows)
-                lr += rows
-        src_idx = torch.from_numpy(src).to(dev)
 
     # a non-default torch stream: kernel, events, RCCL gather and de-interleave are all ordered on it
     stream = torch.cuda.Stream(dev)
@@ -121,11 +107,7 @@ def main():
         scene.render_device(params, slice_t.data_ptr(), counters.data_ptr(), collect_counters=collect, stream=stream.cuda_stream)
         if i is not None:
             ev[i][1].record(stream)
-        if world > 1:
-            dist.gather(slice_t, gathered, dst=0)
-            if rank == 0:
-                torch.index_select(torch.cat(gathered, 0), 0, src_idx, out=frame)
-        # world == 1: slice_t already is the frame
+        fg.run()   # RCCL gather of the u8 slices to rank 0 + de-interleave (no-op for one GPU: the slice is the frame)
 
     # one untimed counting pass: rays, box tests, primitive tests per frame of this rank
     counters.zero_()

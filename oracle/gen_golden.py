@@ -339,6 +339,26 @@ def prepare_scene_text(case):
     return text
 
 
+# Stochastic cases (north_star: "a PSNR bound against a high-spp reference for stochastic features"): the reference
+# itself, seeded RNG shim, single thread.  Stored: a high-spp image and an independent low-spp image whose PSNR against
+# the high-spp one is the bar an equally sampled GPU render has to reach (minus 0.5 dB).
+def stochastic_cases():
+    c = []
+
+    def add(name, scene, config, flags, res=(96, 54), hi=256, lo=16):
+        c.append(dict(name=name, scene=scene, config=config, flags=list(flags), res=res, own=False, hi=hi, lo=lo))
+
+    add("st_dof", os.path.join(EX, "final", "dof", "dof.txt"), os.path.join(EX, "final", "dof", "config.json"),
+        ["--exposure", "0.04", "--fresnel", "--shadows", "--glossy"])
+    add("st_soft_shadows", os.path.join(EX, "final", "soft_shadows", "soft_shadows.txt"), os.path.join(EX, "final", "soft_shadows", "config.json"),
+        ["--exposure", "0.04", "--shadows"])
+    add("st_motion_blur", os.path.join(EX, "final", "motion_blur", "motion_blur.txt"), os.path.join(EX, "final", "motion_blur", "config.json"),
+        ["--exposure", "0.2", "--shadows", "--motion-blur", "0.5"])
+    add("st_glossy", os.path.join(EX, "final", "glossy", "glossy.txt"), os.path.join(EX, "final", "glossy", "config.json"),
+        ["--exposure", "0.04", "--glossy"])
+    return c
+
+
 def main():
     make_textures()
     for d in ("scenes", "configs", "images"):
@@ -358,6 +378,23 @@ def main():
         manifest[name] = dict(flags=case["flags"], rng="d0", width=int(img.shape[1]), height=int(img.shape[0]),
                               source=("own scene (oracle/gen_golden.py)" if case["own"] else os.path.relpath(case["scene"], REF)))
         print("%-26s %4dx%-4d mean %.2f" % (name, img.shape[1], img.shape[0], img.mean()))
+    for case in stochastic_cases():
+        text = prepare_scene_text(case)
+        with open(case["config"]) as f:
+            cfg = f.read()
+        name = case["name"]
+        hi, _ = run_ref.run_reference(text, cfg, flags=case["flags"] + ["--aa", str(case["hi"])], rng="seed:1", texture_dirs=[TEX], threads=1)
+        lo, _ = run_ref.run_reference(text, cfg, flags=case["flags"] + ["--aa", str(case["lo"])], rng="seed:2", texture_dirs=[TEX], threads=1)
+        with open(os.path.join(GOLD, "scenes", name + ".txt"), "w", newline="") as f:
+            f.write(text)
+        with open(os.path.join(GOLD, "configs", name + ".json"), "w") as f:
+            f.write(cfg)
+        np.savez_compressed(os.path.join(GOLD, "images", name + ".npz"), image=hi, image_lo=lo)
+        mse = np.mean((hi.astype(np.float64) - lo.astype(np.float64)) ** 2)
+        psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+        manifest[name] = dict(flags=case["flags"], rng="seeded", width=int(hi.shape[1]), height=int(hi.shape[0]), spp_hi=case["hi"],
+                              spp_lo=case["lo"], psnr_lo_vs_hi=round(float(psnr), 3), source=os.path.relpath(case["scene"], REF))
+        print("%-26s %4dx%-4d hi %d spp, lo %d spp: PSNR(lo,hi) = %.2f dB" % (name, hi.shape[1], hi.shape[0], case["hi"], case["lo"], psnr))
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

@@ -10,7 +10,8 @@ import raytracer_amd as rt
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 with open(os.path.join(GOLD, "manifest.json")) as _f:
     MANIFEST = json.load(_f)
-CASES = sorted(MANIFEST)
+CASES = sorted(k for k, v in MANIFEST.items() if v["rng"] == "d0")          # deterministic: 8-bit max|diff| <= 1
+STOCHASTIC = sorted(k for k, v in MANIFEST.items() if v["rng"] == "seeded")  # PSNR against a high-spp reference render
 
 
 def flags_to_kwargs(flags):
@@ -64,3 +65,11 @@ def diff_stats(a, b):
 def psnr(a, b):
     mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
     return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def load_stochastic(name, spp, seed):
+    """-> (SceneFile, params at `spp` samples with the seeded RNG, reference hi-spp image, reference lo-spp image,
+    PSNR(lo, hi) of the reference's own two renders)"""
+    scene, params, hi = load_case(name, rng="seeded", aa=spp, seed=seed)
+    lo = np.load(os.path.join(GOLD, "images", name + ".npz"))["image_lo"]
+    return scene, params, hi, lo, MANIFEST[name]["psnr_lo_vs_hi"]

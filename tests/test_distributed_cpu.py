@@ -1,0 +1,65 @@
+"""world_size-2 and -3 gloo runs (CPU) of the multi-GPU frame assembly used by bench.py: every rank fills the slice it
+would have rendered (rows of a known frame, interleaved row tiles), the slices are gathered to rank 0 and
+de-interleaved; rank 0 must end up with the known frame.  The GPU render itself is covered by the -m gpu tests
+(test_row_tile_partition_reassembles)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd.distributed import FrameGather
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, H, tile = 40, int(os.environ["RT_TEST_H"]), int(os.environ["RT_TEST_TILE"])
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)          # same on every rank
+    fg = FrameGather(W, H, tile, torch.device("cpu"))
+    rows = rt.part_rows(H, tile, rank, world)
+    # what rt_render_device writes: this rank's tiles, compacted in tile order
+    n_tiles = (H + tile - 1) // tile
+    mine = np.concatenate([frame[t * tile:min(H, (t + 1) * tile)] for t in range(rank, n_tiles, world)] or [frame[:0]])
+    assert mine.shape[0] == rows
+    fg.slice[:rows] = torch.from_numpy(mine)
+    out = fg.run()
+    if rank == 0:
+        assert out is not None and np.array_equal(out.numpy(), frame), "frame mismatch"
+        # the C-ABI scatter helper must agree with the index-select path
+        chk = np.zeros_like(frame)
+        for k in range(world):
+            rt.part_scatter(fg.gathered[k].numpy()[: rt.part_rows(H, tile, k, world)], chk, tile, k, world)
+        assert np.array_equal(chk, frame)
+        print("OK")
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,height,tile", [(2, 1080 // 8, 8), (3, 70, 16), (2, 9, 4)])
+def test_gather_and_deinterleave(tmp_path, world, height, tile):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, RT_TEST_H=str(height), RT_TEST_TILE=str(tile), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-3000:]
