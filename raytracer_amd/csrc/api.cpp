@@ -58,7 +58,8 @@ int upload(const std::vector<T>& v, T** out) {
 }  // namespace
 
 struct rt_scene_s {
-    HostBvh bvh;
+    HostBvh bvh;                      // reference topology: fixes the primitive (visit) order
+    HostBvh trav;                     // what the device traverses (host_bvh.h: build_traversal_bvh)
     int n_shapes = 0;
     int width = 0, height = 0;
     DScene d{};                       // device view (pointers are device pointers)
@@ -257,9 +258,19 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     sc->width = desc->camera.resolution_x;
     sc->height = desc->camera.resolution_y;
     sc->bvh = build_bvh(*desc);
+    {
+        const char* e = std::getenv("RT_BVH_BUILDER");   // "median": traverse the reference topology itself (A/B runs)
+        if (e && std::string(e) == "median") {
+            sc->trav = sc->bvh;
+        } else {
+            std::vector<Box> boxes(desc->n_shapes);
+            for (int k = 0; k < desc->n_shapes; ++k) boxes[k] = shape_bounds(desc->shapes[sc->bvh.order[k]], desc->shutter_time);
+            sc->trav = build_traversal_bvh(boxes, kTravStackDepth - 1);
+        }
+    }
     // Interior levels + the leaf level must fit the per-lane traversal stack (one deferred sibling per level).
-    if (sc->bvh.max_depth + 1 > kTravStackDepth)
-        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->bvh.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + ")");
+    if (sc->trav.max_depth + 1 > kTravStackDepth)
+        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + ")");
     HostArrays h = derive_arrays(*desc, sc->bvh);
 
     DScene& d = sc->d;
@@ -271,7 +282,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     DNode32* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
     double max_origin = 0.0;
     for (int a = 0; a < 3; ++a) max_origin = std::max(max_origin, std::fabs(desc->camera.location[a]));
-    Bvh32 b32 = to_node32(sc->bvh, max_origin);
+    Bvh32 b32 = to_node32(sc->trav, max_origin);
     if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
     if ((rc = upload(h.prims, &d_prims))) return cleanup_fail(rc); track(d_prims);
     if ((rc = upload(h.file_order, &d_forder))) return cleanup_fail(rc); track(d_forder);
@@ -304,9 +315,9 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     d.env_w = d_env ? desc->env.width : 0;
     d.env_h = d_env ? desc->env.height : 0;
     d.n_prims = desc->n_shapes;
-    d.n_nodes = static_cast<int32_t>(sc->bvh.nodes.size());
+    d.n_nodes = static_cast<int32_t>(sc->trav.nodes.size());
     d.n_lights = desc->n_lights;
-    d.root_ref = sc->bvh.root_ref;
+    d.root_ref = sc->trav.root_ref;
     d.features = h.features;
     for (int a = 0; a < 3; ++a) { d.root_lo[a] = b32.root_lo[a]; d.root_hi[a] = b32.root_hi[a]; }
     d.shutter_time = desc->shutter_time;
@@ -329,12 +340,12 @@ void rt_scene_destroy(rt_scene_t scene) {
 
 int rt_scene_bvh_info(rt_scene_t scene, RtBvhInfo* out) {
     if (!scene || !out) return fail(RT_ERR_INVALID, "NULL argument");
-    out->n_nodes = static_cast<int32_t>(scene->bvh.nodes.size());
+    out->n_nodes = static_cast<int32_t>(scene->trav.nodes.size());
     out->n_prims = scene->n_shapes;
-    out->max_depth = scene->bvh.max_depth;
+    out->max_depth = scene->trav.max_depth;
     out->node_bytes = kNodeBytes;
-    store(out->root_min, scene->bvh.root_box.lo);
-    store(out->root_max, scene->bvh.root_box.hi);
+    store(out->root_min, scene->trav.root_box.lo);
+    store(out->root_max, scene->trav.root_box.hi);
     return RT_OK;
 }
 

@@ -15,7 +15,7 @@
 namespace rt {
 
 constexpr int kNodeBytes = 64;        // one DNode32 (what the device traverses)
-constexpr int kTravStackDepth = 24;   // per-lane traversal stack entries (LDS); host refuses deeper trees
+constexpr int kTravStackDepth = 32;   // per-lane traversal stack entries (LDS); host refuses deeper trees
 constexpr int kRayStackDepth = 32;    // per-lane pending-ray stack entries (scratch)
 constexpr int kShadowMaxSegments = 256;
 

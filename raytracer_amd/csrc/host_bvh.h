@@ -31,6 +31,11 @@ struct Bvh32 {
 };
 Bvh32 to_node32(const HostBvh& bvh, double max_abs_origin);
 
+// What the device traverses: a binned-SAH hierarchy with single-primitive leaves over `boxes` (one per primitive,
+// indexed by the reference's depth-first order, so that leaf references are primitive indices).  At most max_depth
+// interior levels (the per-lane traversal stack), falling back to balanced splits where the bound is tight.
+HostBvh build_traversal_bvh(const std::vector<Box>& boxes, int max_depth);
+
 // n_shapes == 0 yields an empty hierarchy (root_ref is a leaf of zero primitives; callers must check).
 HostBvh build_bvh(const RtSceneDesc& desc);
 
