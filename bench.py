@@ -33,7 +33,7 @@ from raytracer_amd import workloads  # noqa: E402
 from raytracer_amd.distributed import FrameGather  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NODE_BYTES_PER_BOX = 32   # one 64-byte DNode32 carries two FP32 child boxes (device_types.h)
+NODE_BYTES = 64           # one DNode4: four quantised child boxes + child references (device_types.h)
 SPHERE_BYTES = 16 + 144   # DPrim header + DXform (device_types.h)
 RAY_STATE_BYTES = 16      # amortised framebuffer + ray state traffic per ray
 
@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the same frame")
     ap.add_argument("--cpu-passes", type=int, default=6, help="CPU baseline: frames rendered (sized for ~10 s of CPU work)")
@@ -91,23 +93,29 @@ def main():
     params.tile_rows, params.part_index, params.part_count = args.tile_rows, rank, world
     scene = rt.Scene(scene_desc)  # BVH build + upload: outside the timed region (scene resident in HBM)
     W, H = args.width, args.height
-    fg = FrameGather(W, H, args.tile_rows, dev)   # slice buffer, gather buffers and de-interleave index (rank 0)
-    slice_t = fg.slice
-    counters = torch.zeros(4, dtype=torch.int64, device=dev)
-
-    # a non-default torch stream: kernel, events, RCCL gather and de-interleave are all ordered on it
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
+    # Frames are independent, so F of them are kept in flight: slot s = step % F has its own non-default HIP stream, ray
+    # queues (inside the library, per stream) and slice / gather / frame buffers.  Within a slot, kernels, events, the RCCL
+    # gather and the de-interleave are ordered on the slot's stream; across slots the tail of one frame's traversal (a few
+    # long rays) overlaps the bulk of the next frame's.  Collectives are issued by this one thread in step order on
+    # every rank.
+    F = max(1, args.frames_in_flight)
+    streams = [torch.cuda.Stream(dev) for _ in range(F)]
+    gathers = [FrameGather(W, H, args.tile_rows, dev) for _ in range(F)]   # slice, gather buffers, de-interleave index (rank 0)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)   # RT_N_COUNTERS
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i=None, collect=False):
-        if i is not None:
-            ev[i][0].record(stream)
-        # counters[3] accumulates the device time of the k_traverse launches (hipEvents inside the library, same stream)
-        scene.render_device(params, slice_t.data_ptr(), counters.data_ptr(), collect_counters=collect, stream=stream.cuda_stream)
-        if i is not None:
-            ev[i][1].record(stream)
-        fg.run()   # RCCL gather of the u8 slices to rank 0 + de-interleave (no-op for one GPU: the slice is the frame)
+    def step(i=None, collect=False, slot=None):
+        if slot is None:
+            slot = 0 if i is None else i % F
+        stream, fg = streams[slot], gathers[slot]
+        with torch.cuda.stream(stream):
+            if i is not None:
+                ev[i][0].record(stream)
+            scene.render_device(params, fg.slice.data_ptr(), counters.data_ptr() if collect else None, collect_counters=collect,
+                                stream=stream.cuda_stream)
+            if i is not None:
+                ev[i][1].record(stream)
+            fg.run()   # RCCL gather of the u8 slices to rank 0 + de-interleave (no-op for one GPU: the slice is the frame)
 
     # one untimed counting pass: rays, box tests, primitive tests per frame of this rank
     counters.zero_()
@@ -120,13 +128,15 @@ def main():
         c_all = tot.cpu().numpy()
     else:
         c_all = c
-    rays_frame, boxes_frame, prims_frame = int(c_all[0]), int(c_all[1]), int(c_all[2])
-    rays_rank, boxes_rank, prims_rank = int(c[0]), int(c[1]), int(c[2])
+    rays_frame, boxes_frame, prims_frame, nodes_frame = int(c_all[0]), int(c_all[1]), int(c_all[2]), int(c_all[4])
+    rays_rank, prims_rank, nodes_rank = int(c[0]), int(c[2]), int(c[4])
 
-    for _ in range(args.warmup):
-        step()
+    for w in range(args.warmup):
+        for slot in range(F):   # every slot allocates its queues and RCCL warms up
+            step(slot=slot)
     torch.cuda.synchronize(dev)
-    counters.zero_()
+    for s in streams:
+        scene.traverse_time(s.cuda_stream)   # drop the warm-up launches from the kernel timing
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -142,13 +152,16 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    render_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
-    traverse_ms = float(counters[3].item()) * 1e-6 / max(1, args.steps)   # per frame == per launch on this workload
+    render_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0   # latency of one frame's kernels
+    # device time of the k_traverse launches of the timed region (hipEvents recorded by the library on the launch streams)
+    tt = [scene.traverse_time(s.cuda_stream) for s in streams]
+    launches = sum(n for _, n in tt)
+    traverse_ms = sum(ms for ms, _ in tt) / max(1, launches)   # average launch duration (one launch per frame here)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = rays_frame * args.steps / elapsed / 1e6
-        alg_bytes = boxes_rank * NODE_BYTES_PER_BOX + prims_rank * SPHERE_BYTES + rays_rank * RAY_STATE_BYTES
+        alg_bytes = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES + rays_rank * RAY_STATE_BYTES
         achieved = alg_bytes / (traverse_ms * 1e-3) / 1e9 if traverse_ms > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -167,14 +180,17 @@ def main():
                                    % (args.spheres, W, H),
                        "partition": "interleaved row tiles of %d rows over %d GPU(s), u8 slices gathered to rank 0 (RCCL)"
                                     % (args.tile_rows, world),
-                       "rays_per_frame": rays_frame, "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
-                       "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)"},
+                       "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
+                       "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
+                       "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
+                       "frames_in_flight": F},
             "ms_per_frame": round(ms_per_step, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "render_ms": round(render_ms, 4),
+                         "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches,
+                         "frame_latency_ms": round(render_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_ray": "32*box_tests + 160*sphere_tests + 16"},
+                         "bytes_per_ray": "64*node_fetches + 160*sphere_tests + 16"},
         }
         if world == 1 and not args.no_cpu_baseline:
             p1 = params.copy()

@@ -172,6 +172,8 @@ typedef struct RtRenderParams {
     int32_t schedule;            /* RT_SCHEDULE_*: how the device evaluates the ray tree (same pixels either way) */
 } RtRenderParams;
 
+#define RT_N_COUNTERS 8
+
 typedef struct RtStats {
     uint64_t rays;            /* closest-hit queries == reference world.intersect calls (tracer.h:156, shading.h:45) */
     uint64_t nodes_visited;   /* BVH node boxes tested   (filled only when collect_counters != 0) */
@@ -179,6 +181,7 @@ typedef struct RtStats {
     double kernel_ms;         /* device time of the whole render (all kernels, hipEvent)            */
     double traverse_ms;       /* of which: the BVH traversal kernel launches (wavefront schedule)   */
     double total_ms;          /* wall time of the call incl. copies                                */
+    uint64_t nodes_fetched;   /* 64-byte hierarchy nodes fetched (each holds up to four child boxes; same)   */
 } RtStats;
 
 typedef struct rt_scene_s* rt_scene_t;
@@ -226,10 +229,17 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
 
 /* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t, NULL = the library's
  * stream): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice
- * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to 4 uint64 (rays, box tests,
- * primitive tests, nanoseconds spent in the traversal kernel) that the kernel adds into; collect_counters!=0 additionally counts node/primitive tests. */
+ * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to RT_N_COUNTERS (8) uint64 (rays, box tests,
+ * primitive tests, nanoseconds spent in the traversal kernel, hierarchy nodes fetched, most nodes fetched by one ray, most scheduler iterations of one wave, reserved) that the
+ * kernel adds into (the two maxima are max-combined); collect_counters!=0 additionally counts node/primitive tests. */
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);
+
+/* Device time (hipEvents on the launch stream) of the BVH-traversal kernel launches that rt_render_device enqueued on
+ * `hip_stream` for this scene since the last call of this function, and how many launches that was.  The stream must
+ * have been synchronised by the caller (RT_ERR_DEVICE otherwise).  No counterpart in the reference: it feeds the
+ * roofline figure of bench.py (the reference only has wall-clock timing, main.cpp:271,350-358). */
+int rt_traverse_time(rt_scene_t scene, void* hip_stream, double* ms_out, uint64_t* launches_out);
 
 /* Number of image rows owned by (part_index, part_count) for a frame of `height` rows cut into `tile_rows` tiles. */
 int rt_part_rows(int height, int tile_rows, int part_index, int part_count);

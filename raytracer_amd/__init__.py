@@ -89,7 +89,8 @@ class RtRenderParams(C.Structure):
 
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("kernel_ms", C.c_double), ("traverse_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("traverse_ms", C.c_double), ("total_ms", C.c_double),
+                ("nodes_fetched", C.c_uint64)]
 
 
 class RtBvhInfo(C.Structure):
@@ -109,7 +110,7 @@ ABI_SYMBOLS = [
     "rt_config_parse", "rt_config_get_int", "rt_config_get_double", "rt_config_get_bool", "rt_config_destroy",
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
-    "rt_version",
+    "rt_version", "rt_traverse_time",
 ]
 
 
@@ -124,6 +125,7 @@ def _load():
         "rt_scene_create": (i32, [C.POINTER(RtSceneDesc), C.POINTER(vp)]), "rt_scene_destroy": (None, [vp]),
         "rt_scene_bvh_info": (i32, [vp, C.POINTER(RtBvhInfo)]),
         "rt_bvh_build_host": (i32, [C.POINTER(RtSceneDesc), C.POINTER(RtBvhInfo), C.POINTER(C.c_int32)]),
+        "rt_traverse_time": (i32, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
         "rt_part_rows": (i32, [i32, i32, i32, i32]),
@@ -371,6 +373,12 @@ class Scene:
     def render_device(self, params, d_rgb8_ptr, d_counters_ptr=None, collect_counters=False, stream=None):
         """Asynchronous render of this part's rows into device memory (see rt_render_device)."""
         _check(lib.rt_render_device(self._h, C.byref(params), d_rgb8_ptr, d_counters_ptr, int(collect_counters), stream))
+
+    def traverse_time(self, stream=None):
+        """(ms, launches) of the traversal-kernel launches enqueued on `stream` since the last call (stream synchronised)."""
+        ms, n = C.c_double(0.0), C.c_uint64(0)
+        _check(lib.rt_traverse_time(self._h, stream, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,7 +44,7 @@ struct DeviceState {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint64_t* d_counters = nullptr;  // 4 x u64
+    uint64_t* d_counters = nullptr;  // RT_N_COUNTERS x u64
 };
 DeviceState g_dev;
 
@@ -61,11 +63,13 @@ struct rt_scene_s {
     HostBvh bvh;                      // reference topology: fixes the primitive (visit) order
     HostBvh trav;                     // what the device traverses (host_bvh.h: build_traversal_bvh)
     int n_shapes = 0;
+    int32_t n_nodes4 = 0, depth4 = 0;   // the 4-wide device image of trav
     int width = 0, height = 0;
     DScene d{};                       // device view (pointers are device pointers)
     std::vector<void*> allocations;   // everything to hipFree
     uint8_t* d_frame = nullptr;       // scratch framebuffer for rt_render
-    WavefrontWorkspace wf;            // queues / accumulators of the wavefront schedule
+    std::map<hipStream_t, WavefrontWorkspace> wf;   // queues / accumulators of the wavefront schedule, one set per stream
+    std::mutex wf_mutex;              // guards the map (not the workspaces: one render at a time per stream)
     size_t d_frame_bytes = 0;
     bool on_device = false;
 };
@@ -110,6 +114,7 @@ struct HostArrays {
     std::vector<DMaterial> materials;
     std::vector<DLight> lights;
     int32_t features = 0;
+    int32_t spawning_materials = 0;
     DCamera cam{};
 };
 
@@ -164,6 +169,7 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
         o.is_metal = m.is_metal ? 1 : 0;
         o.pad = 0;
         if (o.texture >= 0 || o.bump >= 0) h.features |= RT_FEAT_TEXTURE;
+        if (!(m.reflectivity <= 0.0) || !(m.transparency <= 0.0)) h.spawning_materials = 1;   // also NaN
     }
     h.lights.resize(d.n_lights);
     for (int i = 0; i < d.n_lights; ++i) {
@@ -213,7 +219,7 @@ int rt_init(int device_id) {
     HIP_TRY(hipStreamCreateWithFlags(&g_dev.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g_dev.ev0));
     HIP_TRY(hipEventCreate(&g_dev.ev1));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_dev.d_counters), 4 * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_dev.d_counters), RT_N_COUNTERS * sizeof(uint64_t)));
     g_dev.ready = true;
     return RT_OK;
 }
@@ -265,12 +271,12 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         } else {
             std::vector<Box> boxes(desc->n_shapes);
             for (int k = 0; k < desc->n_shapes; ++k) boxes[k] = shape_bounds(desc->shapes[sc->bvh.order[k]], desc->shutter_time);
-            sc->trav = build_traversal_bvh(boxes, kTravStackDepth - 1);
+            sc->trav = build_traversal_bvh(boxes, kMaxBinaryDepth);
         }
     }
-    // Interior levels + the leaf level must fit the per-lane traversal stack (one deferred sibling per level).
-    if (sc->trav.max_depth + 1 > kTravStackDepth)
-        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + ")");
+    // A 4-wide node defers at most three children per level, and the collapsed tree is never deeper than the binary one.
+    if (3 * sc->trav.max_depth > kTravStackDepth)
+        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + " entries)");
     HostArrays h = derive_arrays(*desc, sc->bvh);
 
     DScene& d = sc->d;
@@ -279,10 +285,12 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         for (void* p : sc->allocations) (void)hipFree(p);
         return code;
     };
-    DNode32* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
+    DNode4* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
     double max_origin = 0.0;
     for (int a = 0; a < 3; ++a) max_origin = std::max(max_origin, std::fabs(desc->camera.location[a]));
-    Bvh32 b32 = to_node32(sc->trav, max_origin);
+    Bvh4 b32 = to_node4(sc->trav, max_origin);
+    sc->n_nodes4 = static_cast<int32_t>(b32.nodes.size());
+    sc->depth4 = b32.max_depth;
     if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
     if ((rc = upload(h.prims, &d_prims))) return cleanup_fail(rc); track(d_prims);
     if ((rc = upload(h.file_order, &d_forder))) return cleanup_fail(rc); track(d_forder);
@@ -315,10 +323,12 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     d.env_w = d_env ? desc->env.width : 0;
     d.env_h = d_env ? desc->env.height : 0;
     d.n_prims = desc->n_shapes;
-    d.n_nodes = static_cast<int32_t>(sc->trav.nodes.size());
+    d.n_nodes = sc->n_nodes4;
     d.n_lights = desc->n_lights;
-    d.root_ref = sc->trav.root_ref;
+    d.root_ref = b32.root_ref;
     d.features = h.features;
+    d.spawning_materials = h.spawning_materials;
+    d.pad_root = 0;
     for (int a = 0; a < 3; ++a) { d.root_lo[a] = b32.root_lo[a]; d.root_hi[a] = b32.root_hi[a]; }
     d.shutter_time = desc->shutter_time;
     d.cam = h.cam;
@@ -333,16 +343,16 @@ void rt_scene_destroy(rt_scene_t scene) {
         (void)hipSetDevice(g_dev.device);
         for (void* p : scene->allocations) (void)hipFree(p);
         if (scene->d_frame) (void)hipFree(scene->d_frame);
-        wavefront_workspace_free(scene->wf);
+        for (auto& kv : scene->wf) wavefront_workspace_free(kv.second);
     }
     delete scene;
 }
 
 int rt_scene_bvh_info(rt_scene_t scene, RtBvhInfo* out) {
     if (!scene || !out) return fail(RT_ERR_INVALID, "NULL argument");
-    out->n_nodes = static_cast<int32_t>(scene->trav.nodes.size());
+    out->n_nodes = scene->n_nodes4;
     out->n_prims = scene->n_shapes;
-    out->max_depth = scene->trav.max_depth;
+    out->max_depth = scene->depth4;
     out->node_bytes = kNodeBytes;
     store(out->root_min, scene->trav.root_box.lo);
     store(out->root_max, scene->trav.root_box.hi);
@@ -416,8 +426,34 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     if (params->schedule == RT_SCHEDULE_MEGAKERNEL)
         e = launch_render_mega(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
     else
-        e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st, scene->wf);
+    {
+        WavefrontWorkspace* ws;
+        {
+            std::lock_guard<std::mutex> lock(scene->wf_mutex);
+            ws = &scene->wf[st];   // std::map: references stay valid when other streams are added
+        }
+        e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st, *ws);
+    }
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_traverse_time(rt_scene_t scene, void* hip_stream, double* ms_out, uint64_t* launches_out) {
+    if (!scene || !ms_out || !launches_out) return fail(RT_ERR_INVALID, "NULL argument");
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
+    WavefrontWorkspace* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(scene->wf_mutex);
+        auto it = scene->wf.find(st);
+        if (it != scene->wf.end()) ws = &it->second;
+    }
+    *ms_out = 0.0;
+    *launches_out = 0;
+    if (!ws) return RT_OK;
+    unsigned launches = 0;
+    hipError_t e = wavefront_traverse_time(*ws, ms_out, &launches);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("traversal events: ") + hipGetErrorString(e));
+    *launches_out = launches;
     return RT_OK;
 }
 
@@ -432,13 +468,12 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
     size_t bytes = static_cast<size_t>(rows) * scene->width * 3;
     if (scene->d_frame_bytes < bytes) {
         if (scene->d_frame) (void)hipFree(scene->d_frame);
-        wavefront_workspace_free(scene->wf);
         scene->d_frame = nullptr;
         scene->d_frame_bytes = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame), bytes ? bytes : 1));
         scene->d_frame_bytes = bytes;
     }
-    HIP_TRY(hipMemsetAsync(g_dev.d_counters, 0, 4 * sizeof(uint64_t), g_dev.stream));
+    HIP_TRY(hipMemsetAsync(g_dev.d_counters, 0, RT_N_COUNTERS * sizeof(uint64_t), g_dev.stream));
     HIP_TRY(hipEventRecord(g_dev.ev0, g_dev.stream));
     int rc = rt_render_device(scene, params, scene->d_frame, g_dev.d_counters, stats != nullptr, g_dev.stream);
     if (rc) return rc;
@@ -447,7 +482,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
     uint8_t* dst = rgb8_out;
     if (parts > 1) { slice.resize(bytes); dst = slice.data(); }
     if (bytes) HIP_TRY(hipMemcpyAsync(dst, scene->d_frame, bytes, hipMemcpyDeviceToHost, g_dev.stream));
-    uint64_t counters[4] = {0, 0, 0, 0};
+    uint64_t counters[RT_N_COUNTERS] = {};
     HIP_TRY(hipMemcpyAsync(counters, g_dev.d_counters, sizeof(counters), hipMemcpyDeviceToHost, g_dev.stream));
     HIP_TRY(hipStreamSynchronize(g_dev.stream));
     if (parts > 1 && bytes) {
@@ -460,6 +495,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
         stats->rays = counters[0];
         stats->nodes_visited = counters[1];
         stats->prims_tested = counters[2];
+        stats->nodes_fetched = counters[4];
         stats->kernel_ms = ms;
         stats->traverse_ms = static_cast<double>(counters[3]) * 1e-6;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

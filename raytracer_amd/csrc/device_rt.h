@@ -345,16 +345,56 @@ __device__ bool march_complex(const DScene& S, const DParams& P, const DPrim& pr
     return false;
 }
 
-// Per-lane traversal stack living in LDS: entry i of this lane is base[i * stride] (stride = threads per block, so
-// that the lanes of a wave hit 64 consecutive banks).
+// Per-lane traversal stack of (child reference, entry distance) pairs.  The first kTravLdsEntries entries live in
+// LDS: entry i of this lane is lds[i * stride] (stride = threads per block, so that the lanes of a wave fall on
+// consecutive banks); deeper entries, which only unbalanced hierarchies reach, go to per-lane scratch memory.
 struct TravStack {
-    int* base;
+    unsigned long long* lds;
     int stride;
-    __device__ __forceinline__ int& at(int i) const { return base[i * stride]; }
+    unsigned long long spill[kTravSpillEntries];
+    __device__ __forceinline__ void push(int& sp, int ref, float t) {
+        const unsigned long long v = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)ref;
+        if (sp < kTravLdsEntries) lds[sp * stride] = v;
+        else spill[sp - kTravLdsEntries] = v;
+        ++sp;
+    }
+    // Defers `count` (0..3) entries; (r1, t1) ends on top, then (r2, t2), then (r3, t3): an entry k is real when
+    // k <= count.  With room in LDS for all three the stores are unconditional (unused ones go to the discard row
+    // kTravLdsEntries), so the usual case has no branch at all.
+    __device__ __forceinline__ void push_sorted(int& sp, int count, int r1, float t1, int r2, float t2, int r3, float t3) {
+        if (__builtin_expect(sp + 3 <= kTravLdsEntries, 1)) {
+            const int s1 = count >= 1 ? sp + count - 1 : kTravLdsEntries;
+            const int s2 = count >= 2 ? sp + count - 2 : kTravLdsEntries;
+            const int s3 = count >= 3 ? sp : kTravLdsEntries;
+            lds[s1 * stride] = ((unsigned long long)__float_as_uint(t1) << 32) | (unsigned)r1;
+            lds[s2 * stride] = ((unsigned long long)__float_as_uint(t2) << 32) | (unsigned)r2;
+            lds[s3 * stride] = ((unsigned long long)__float_as_uint(t3) << 32) | (unsigned)r3;
+            sp += count;
+        } else {
+            if (count >= 3) push(sp, r3, t3);
+            if (count >= 2) push(sp, r2, t2);
+            if (count >= 1) push(sp, r1, t1);
+        }
+    }
+    // Next deferred child whose box the ray enters before tmax (the closest hit so far), or kDoneRef.
+    __device__ __forceinline__ int pop(int& sp, float tmax) {
+        while (sp > 0) {
+            --sp;
+            unsigned long long v;
+            if (__builtin_expect(sp < kTravLdsEntries, 1)) {
+                v = lds[sp * stride];
+            } else {
+                v = spill[sp - kTravLdsEntries];
+                asm volatile("" : "+v"(v));   // keeps the two loads apart (merged, they become one flat load)
+            }
+            if (__uint_as_float((unsigned)(v >> 32)) <= tmax) return (int)(unsigned)v;
+        }
+        return 0x7fffffff;
+    }
 };
 
 struct Counters {
-    unsigned int rays, nodes, prims;
+    unsigned int rays, nodes, prims, visits;   // closest-hit queries, box tests, primitive tests, interior nodes fetched
 };
 
 // Compile-time feature set of a kernel variant (RT_FEAT_* bits of device_types.h).  A scene is rendered by the
@@ -380,11 +420,15 @@ __device__ __forceinline__ bool tie_new_wins(bool new_incl, int new_order, bool 
 }
 
 // One primitive against the ray; updates `best` when it is the new closest hit.
-template <int F>
+template <int F, bool COUNT = true>
 __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, const Ray& r, int prim, int order, double tmin,
                                           Cand& best, int& best_order, bool& best_incl, Counters& C) {
-    const DPrim pr = S.prims[prim];
-    if (P.count_tests) C.prims++;
+    // A scene of plain spheres only (the kernel variant F says so) has one DXform per primitive in primitive order
+    // (api.cpp: derive_arrays), so the header need not be fetched before the transform: one memory round trip per test.
+    DPrim pr;
+    if (F == RT_FEAT_SPHERE) { pr.type = RT_SHAPE_SPHERE; pr.data = prim; pr.material = 0; pr.file_index = 0; }
+    else pr = S.prims[prim];
+    if (COUNT && P.count_tests) C.prims++;
     double t = 0.0, bu = 0.0, bv = 0.0;
     int tri = 0;
     bool hit = false, incl = true;
@@ -485,11 +529,13 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
 // node are issued together (one memory round trip per node).
 struct RayF {
     float inv[3], oi[3];   // 1/d and o * (1/d), per axis
+    unsigned neg[3];       // all ones where the direction component is negative (the near plane is then the upper one)
 };
 __device__ __forceinline__ RayF make_rayf(const Ray& r) {
     RayF f;
     f.inv[0] = (float)(1.0 / r.d.x); f.inv[1] = (float)(1.0 / r.d.y); f.inv[2] = (float)(1.0 / r.d.z);
     f.oi[0] = (float)r.o.x * f.inv[0]; f.oi[1] = (float)r.o.y * f.inv[1]; f.oi[2] = (float)r.o.z * f.inv[2];
+    f.neg[0] = f.inv[0] < 0.f ? ~0u : 0u; f.neg[1] = f.inv[1] < 0.f ? ~0u : 0u; f.neg[2] = f.inv[2] < 0.f ? ~0u : 0u;
     return f;
 }
 // t = B * inv - o * inv with one FMA per plane; the extra rounding of o*inv is of the size of the origin's own FP32
@@ -510,31 +556,94 @@ __device__ __forceinline__ bool box_test32(const float* lo, const float* hi, con
     return tf >= tn;
 }
 
-// One interior node pulled into registers with four 16-byte loads issued back to back.
-typedef float rt_f4 __attribute__((ext_vector_type(4)));
+// One 4-wide node (device_types.h: DNode4) pulled into registers with four 16-byte loads issued back to back.
+typedef unsigned rt_u4 __attribute__((ext_vector_type(4)));
 struct NodeRegs {
-    float lo[2][3], hi[2][3];
-    int child[2];
+    float org[3];
+    unsigned exps, qlo[3], qhi[3];
+    int child[4];
 };
-__device__ __forceinline__ NodeRegs load_node(const DNode32* n) {
-    const rt_f4* p = reinterpret_cast<const rt_f4*>(n);
-    const rt_f4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+__device__ __forceinline__ NodeRegs load_node(const DNode4* n) {
+    const rt_u4* p = reinterpret_cast<const rt_u4*>(n);
+    const rt_u4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
     NodeRegs r;
-    r.lo[0][0] = a0.x; r.lo[0][1] = a0.y; r.lo[0][2] = a0.z;
-    r.lo[1][0] = a0.w; r.lo[1][1] = a1.x; r.lo[1][2] = a1.y;
-    r.hi[0][0] = a1.z; r.hi[0][1] = a1.w; r.hi[0][2] = a2.x;
-    r.hi[1][0] = a2.y; r.hi[1][1] = a2.z; r.hi[1][2] = a2.w;
-    r.child[0] = __float_as_int(a3.x);
-    r.child[1] = __float_as_int(a3.y);
+    r.org[0] = __uint_as_float(a0.x); r.org[1] = __uint_as_float(a0.y); r.org[2] = __uint_as_float(a0.z);
+    r.exps = a0.w;
+    r.qlo[0] = a1.x; r.qlo[1] = a1.y; r.qlo[2] = a1.z;
+    r.qhi[0] = a1.w; r.qhi[1] = a2.x; r.qhi[2] = a2.y;
+    r.child[0] = (int)a2.z; r.child[1] = (int)a2.w; r.child[2] = (int)a3.x; r.child[3] = (int)a3.y;
     return r;
 }
 
+// The four child boxes of a node against the ray.  Planes are org + q * 2^e on the node's grid, so the slab distance is
+// t = q * (2^e * inv) + (org * inv - o * inv): two per-axis constants per node and one FMA per plane (issued as packed
+// pairs: near and far plane of one axis).  Which plane is the near one follows from the sign of the direction, so the
+// two plane words of an axis are swapped once per node instead of ordering every pair of distances.  Conservative in
+// the same way as box_test32 (absolute errors are in the host pad, host_bvh.cpp: to_node4; relative ones in kSlack;
+// NaNs of axis-parallel rays drop out of min3/max3).  e[c] = entry distance of child c, +inf when missed/unused.
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, float tmin, float tmax, float e[4]) {
+    constexpr float kSlack = 4.76837158e-7f;  // 2^-21
+    rt_f2 a[3], b[3];
+    unsigned qn[3], qf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float ak = __uint_as_float(((n.exps >> (8 * k)) & 0xffu) << 23) * f.inv[k];   // power of two: exact
+        const float bk = fmaf(n.org[k], f.inv[k], -f.oi[k]);
+        a[k] = rt_f2{ak, ak};
+        b[k] = rt_f2{bk, bk};
+        const unsigned d = (n.qlo[k] ^ n.qhi[k]) & f.neg[k];
+        qn[k] = n.qlo[k] ^ d;
+        qf[k] = n.qhi[k] ^ d;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        rt_f2 t[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const rt_f2 q{(float)((qn[k] >> (8 * c)) & 0xffu), (float)((qf[k] >> (8 * c)) & 0xffu)};
+            t[k] = __builtin_elementwise_fma(q, a[k], b[k]);
+        }
+        float tn = fmaxf(fmaxf(t[0].x, t[1].x), t[2].x);
+        float tf = fminf(fminf(t[0].y, t[1].y), t[2].y);
+        tn = fmaf(-fabsf(tn), kSlack, tn);
+        tf = fmaf(fabsf(tf), kSlack, tf);
+        tn = fmaxf(tn, tmin);
+        tf = fminf(tf, tmax);
+        e[c] = (tf >= tn && n.child[c] != kEmptyChild) ? tn : INFINITY;
+    }
+}
+
+// One traversal step at an interior node: returns the nearest child entered (or the next deferred one) and defers the
+// other entered children, farthest first, so that they are popped nearest first.
+__device__ __forceinline__ int node4_step(const NodeRegs& n, const RayF& f, float tmin, float tmax, TravStack& stack, int& sp) {
+    float e[4];
+    node4_test(n, f, tmin, tmax, e);
+    int c[4] = {n.child[0], n.child[1], n.child[2], n.child[3]};
+#define RT_CSWAP(i, j)                                                      \
+    {                                                                       \
+        const bool sw = e[j] < e[i];                                        \
+        const float te = sw ? e[j] : e[i], tf_ = sw ? e[i] : e[j];          \
+        const int tc = sw ? c[j] : c[i], td = sw ? c[i] : c[j];             \
+        e[i] = te; e[j] = tf_; c[i] = tc; c[j] = td;                        \
+    }
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+    if (e[0] == INFINITY) return stack.pop(sp, tmax);
+    const int deferred = (e[1] != INFINITY) + (e[2] != INFINITY) + (e[3] != INFINITY);
+    stack.push_sorted(sp, deferred, c[1], e[1], c[2], e[2], c[3], e[3]);
+    return c[0];
+}
+__device__ __forceinline__ int node4_children(const NodeRegs& n) {
+    return (n.child[0] != kEmptyChild) + (n.child[1] != kEmptyChild) + (n.child[2] != kEmptyChild) + (n.child[3] != kEmptyChild);
+}
+
 // Closest hit == `world.intersect(r, tmin, tmax, rec)` (hittable_list.cpp:8-33 over bvh.cpp:101-114).
-// Traversal is front-to-back with a per-lane stack of deferred children in LDS; the hit found equals the
-// reference's left-then-right recursion because closest-hit selection is order independent (ties: tie_new_wins).
+// Traversal is front-to-back with a per-lane stack of deferred children; the hit found equals the reference's
+// left-then-right recursion because closest-hit selection is order independent (ties: tie_new_wins).
 template <int F>
 __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, double tmin, double tmax, Cand& best, Counters& C,
-                            TravStack stack) {
+                            TravStack& stack) {
     C.rays++;
     best.t = tmax;
     best.prim = -1;
@@ -551,7 +660,8 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
     const float tmin32 = __double2float_rd(tmin);
     float e;
     if (P.count_tests) C.nodes++;
-    if (!box_test32(S.root_lo, S.root_hi, rf, tmin32, __double2float_ru(tmax), e)) return false;
+    float tmax32 = __double2float_ru(tmax);   // follows best.t (rounded up)
+    if (!box_test32(S.root_lo, S.root_hi, rf, tmin32, tmax32, e)) return false;
     int sp = 0;
     int cur = S.root_ref;
     constexpr int kDone = 0x7fffffff;
@@ -561,30 +671,16 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
     while (cur != kDone) {
         while (static_cast<unsigned>(cur) < static_cast<unsigned>(kDone)) {  // 0 <= cur < kDone: interior node
             const NodeRegs n = load_node(&S.nodes[cur]);
-            if (P.count_tests) C.nodes += 2;
-            float e0, e1;
-            const float tmax32 = __double2float_ru(best.t);
-            bool h0 = box_test32(n.lo[0], n.hi[0], rf, tmin32, tmax32, e0);
-            bool h1 = box_test32(n.lo[1], n.hi[1], rf, tmin32, tmax32, e1);
-            int c0 = n.child[0], c1 = n.child[1];
-            if (h0 && h1) {
-                bool left_first = !(e1 < e0);
-                stack.at(sp++) = left_first ? c1 : c0;
-                cur = left_first ? c0 : c1;
-            } else if (h0) {
-                cur = c0;
-            } else if (h1) {
-                cur = c1;
-            } else {
-                cur = sp ? stack.at(--sp) : kDone;
-            }
+            if (P.count_tests) { C.nodes += node4_children(n); C.visits++; }
+            cur = node4_step(n, rf, tmin32, tmax32, stack, sp);
         }
         if (cur < 0) {  // leaf: one or two consecutive primitives
             int code = ~cur;
             int first = code >> 1;
             test_prim<F>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
             if (code & 1) test_prim<F>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
-            cur = sp ? stack.at(--sp) : kDone;
+            tmax32 = __double2float_ru(best.t);
+            cur = stack.pop(sp, tmax32);
         }
     }
     return best.prim >= 0;

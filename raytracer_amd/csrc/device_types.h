@@ -14,8 +14,11 @@
 
 namespace rt {
 
-constexpr int kNodeBytes = 64;        // one DNode32 (what the device traverses)
-constexpr int kTravStackDepth = 32;   // per-lane traversal stack entries (LDS); host refuses deeper trees
+constexpr int kNodeBytes = 64;        // one DNode4 (what the device traverses)
+constexpr int kTravLdsEntries = 16;   // per-lane traversal stack entries kept in LDS (8 bytes each)
+constexpr int kTravSpillEntries = 80; // further entries in per-lane scratch memory (deep, unbalanced hierarchies only)
+constexpr int kTravStackDepth = kTravLdsEntries + kTravSpillEntries;
+constexpr int kMaxBinaryDepth = 31;   // interior levels of the binary tree; a 4-wide node defers <= 3 children per level
 constexpr int kRayStackDepth = 32;    // per-lane pending-ray stack entries (scratch)
 constexpr int kShadowMaxSegments = 256;
 
@@ -35,17 +38,22 @@ struct alignas(128) DNode {
 };
 static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 
-// What the device actually traverses: the same node with its two child boxes in FP32, widened outward on the host
-// (host_bvh.cpp: to_node32) so that the FP32 slab test of device_rt.h accepts every ray the reference's FP64 test
-// (aabb.cpp:4-38) accepts.  Boxes only cull; every hit/miss decision is made by the FP64 primitive tests, so a
-// conservative (superset) traversal yields the same closest hit.  64 bytes, 64-byte aligned: four 16-byte loads.
-struct alignas(64) DNode32 {
-    float lo[2][3];   // [child][axis]
-    float hi[2][3];
-    int32_t child[2];
+// What the device actually traverses: the binary tree collapsed to four children per node (host_bvh.cpp: to_node4),
+// child boxes quantised to 8 bits per plane on a per-node grid: plane = org[axis] + q * 2^(exp[axis] - 127).  Boxes
+// are moved outward before quantisation (lower planes rounded down, upper planes up), so the FP32 slab test of
+// device_rt.h accepts every ray the reference's FP64 test (aabb.cpp:4-38) accepts on the original boxes.  Boxes only
+// cull; every hit/miss decision is made by the FP64 primitive tests, so a conservative (superset) traversal yields
+// the same closest hit.  64 bytes, 64-byte aligned: four 16-byte loads per lane and visit.
+constexpr int32_t kEmptyChild = 0x7fffffff;
+struct alignas(64) DNode4 {
+    float org[3];        // grid origin (<= every lower plane)
+    uint32_t exps;       // biased FP32 exponent of the grid step per axis: x | y << 8 | z << 16
+    uint32_t qlo[3];     // [axis], byte c = lower plane of child c
+    uint32_t qhi[3];     // [axis], byte c = upper plane of child c
+    int32_t child[4];    // >= 0 interior node, < 0 leaf (make_leaf_ref), kEmptyChild = unused slot
     int32_t pad[2];
 };
-static_assert(sizeof(DNode32) == kNodeBytes, "DNode32 must be 64 bytes");
+static_assert(sizeof(DNode4) == kNodeBytes, "DNode4 must be 64 bytes");
 
 // Per-primitive header, in BVH depth-first (leaf) order.
 struct alignas(16) DPrim {
@@ -112,7 +120,7 @@ struct DCamera {
 
 // Everything the kernel needs to find the scene; passed by value as a kernel argument.
 struct DScene {
-    const DNode32* nodes;
+    const DNode4* nodes;
     const DPrim* prims;           // depth-first order
     const int32_t* file_order;    // file_order[i] = prim index of the i-th shape in the scene file
     const DXform* xforms;
@@ -126,7 +134,8 @@ struct DScene {
     int32_t root_ref;             // reference to the root (node 0 or a leaf)
     int32_t features;             // RT_FEAT_* bits: which code paths this scene can reach
     float root_lo[3], root_hi[3];   // widened like the node boxes
-    int32_t pad_root[2];
+    int32_t spawning_materials;     // 1 when some material reflects or transmits (secondary radiance rays possible)
+    int32_t pad_root;
     double shutter_time;
     DCamera cam;
 };

@@ -267,8 +267,114 @@ static float round_up(double v) {
     return f;
 }
 
-Bvh32 to_node32(const HostBvh& bvh, double max_abs_origin) {
-    Bvh32 out;
+namespace {
+
+struct Collapser {
+    const HostBvh& bvh;
+    double pad;
+    Bvh4& out;
+
+    struct Slot {
+        int32_t ref;
+        Box box;
+    };
+
+    // One 4-wide node for the binary subtree rooted at interior node b; returns its index and depth (levels).
+    std::pair<int32_t, int32_t> emit(int32_t b) {
+        const int32_t me = static_cast<int32_t>(out.nodes.size());
+        out.nodes.emplace_back();
+        std::vector<Slot> slots;
+        auto children_of = [&](int32_t n, Slot& l, Slot& r) {
+            const DNode& nd = bvh.nodes[n];
+            l = Slot{nd.child[0], Box{V3(nd.lo[0]), V3(nd.hi[0])}};
+            r = Slot{nd.child[1], Box{V3(nd.lo[1]), V3(nd.hi[1])}};
+        };
+        Slot l, r;
+        children_of(b, l, r);
+        slots.push_back(l);
+        slots.push_back(r);
+        while (slots.size() < 4) {   // open the interior child with the largest surface: it is the most likely to be entered
+            int pick = -1;
+            double best = -1.0;
+            for (size_t i = 0; i < slots.size(); ++i) {
+                if (slots[i].ref < 0) continue;
+                double a = half_area(slots[i].box);
+                if (!(a <= best)) { best = a; pick = static_cast<int>(i); }
+            }
+            if (pick < 0) break;
+            children_of(slots[pick].ref, l, r);
+            slots[pick] = l;
+            slots.push_back(r);
+        }
+        int32_t depth = 1;
+        int32_t refs[4] = {kEmptyChild, kEmptyChild, kEmptyChild, kEmptyChild};
+        for (size_t i = 0; i < slots.size(); ++i) {
+            if (slots[i].ref >= 0) {
+                auto sub = emit(slots[i].ref);
+                refs[i] = sub.first;
+                depth = std::max(depth, 1 + sub.second);
+            } else {
+                refs[i] = slots[i].ref;
+            }
+        }
+        quantise(out.nodes[me], slots, refs);
+        return {me, depth};
+    }
+
+    void quantise(DNode4& o, const std::vector<Slot>& slots, const int32_t refs[4]) const {
+        o.exps = 0;
+        for (int a = 0; a < 3; ++a) {
+            o.qlo[a] = 0xffffffffu;   // unused slots: lower plane above upper plane
+            o.qhi[a] = 0u;
+        }
+        for (int c = 0; c < 4; ++c) o.child[c] = refs[c];
+        o.pad[0] = o.pad[1] = 0;
+        for (int a = 0; a < 3; ++a) {
+            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+            for (const Slot& s : slots) {
+                lo = std::min(lo, s.box.lo[a] - pad);
+                hi = std::max(hi, s.box.hi[a] + pad);
+            }
+            if (!std::isfinite(lo)) lo = -std::numeric_limits<float>::max();
+            if (!std::isfinite(hi)) hi = std::numeric_limits<float>::max();
+            const float org = round_down(lo);
+            // smallest power-of-two step with 255 steps covering [org, hi]
+            int e = -126;
+            const double ext = hi - static_cast<double>(org);
+            if (ext > 0.0) {
+                int ex;
+                (void)std::frexp(ext / 255.0, &ex);   // ext/255 = m * 2^ex, m in [0.5, 1)  =>  2^ex >= ext/255
+                e = std::max(-126, std::min(127, ex));
+            }
+            auto q_of = [&](double v, bool up, int ee) {
+                double g = (v - static_cast<double>(org)) / std::ldexp(1.0, ee);
+                g = up ? std::ceil(g) : std::floor(g);
+                return g;
+            };
+            while (e < 127 && q_of(hi, true, e) > 255.0) ++e;
+            o.org[a] = org;
+            o.exps |= static_cast<uint32_t>(e + 127) << (8 * a);
+            uint32_t wlo = o.qlo[a], whi = o.qhi[a];
+            for (size_t c = 0; c < slots.size(); ++c) {
+                double ql = q_of(std::max(slots[c].box.lo[a] - pad, static_cast<double>(org)), false, e);
+                double qh = q_of(std::min(slots[c].box.hi[a] + pad, hi), true, e);
+                if (!(ql >= 0.0)) ql = 0.0;       // also NaN
+                if (!(qh <= 255.0)) qh = 255.0;
+                if (ql > 255.0) ql = 255.0;
+                if (qh < 0.0) qh = 0.0;
+                wlo = (wlo & ~(0xffu << (8 * c))) | (static_cast<uint32_t>(ql) << (8 * c));
+                whi = (whi & ~(0xffu << (8 * c))) | (static_cast<uint32_t>(qh) << (8 * c));
+            }
+            o.qlo[a] = wlo;
+            o.qhi[a] = whi;
+        }
+    }
+};
+
+}  // namespace
+
+Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin) {
+    Bvh4 out;
     double m = max_abs_origin;
     auto grow_abs = [&](const double* p) { for (int a = 0; a < 3; ++a) if (std::isfinite(p[a])) m = std::max(m, std::fabs(p[a])); };
     double rl[3], rh[3];
@@ -276,26 +382,23 @@ Bvh32 to_node32(const HostBvh& bvh, double max_abs_origin) {
     store(rh, bvh.root_box.hi);
     grow_abs(rl);
     grow_abs(rh);
-    // ray origins: the camera, and surface points inside the root box moved by at most ~1e-3 (tracer.h:201,
-    // shading.h:68,93).  2^-22 * m = 4x the FP32 rounding of such an origin.
-    out.pad = (m + 0.01) * std::ldexp(1.0, -22);
-    const double pad = out.pad;
-    out.nodes.resize(bvh.nodes.size());
-    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
-        const DNode& n = bvh.nodes[i];
-        DNode32& o = out.nodes[i];
-        for (int c = 0; c < 2; ++c)
-            for (int a = 0; a < 3; ++a) {
-                o.lo[c][a] = round_down(n.lo[c][a] - pad);
-                o.hi[c][a] = round_up(n.hi[c][a] + pad);
-            }
-        o.child[0] = n.child[0];
-        o.child[1] = n.child[1];
-        o.pad[0] = o.pad[1] = 0;
+    // Absolute FP32 errors of the device slab test (device_rt.h: node4_test), in world units, for coordinates bounded
+    // by m: rounding the ray origin (2^-24 m), the product o*inv (2^-24 m), org*inv - o*inv (2^-23 m) -- under
+    // 5 * 2^-24 m in total.  Ray origins are the camera or surface points inside the root box moved by at most ~1e-3
+    // (tracer.h:201, shading.h:68,93).  Relative errors are covered on the device.
+    out.pad = (m + 0.01) * std::ldexp(1.0, -21);
+    out.root_ref = bvh.root_ref;
+    out.max_depth = 0;
+    if (!bvh.nodes.empty() && bvh.root_ref >= 0) {
+        out.nodes.reserve(bvh.nodes.size() / 2 + 16);
+        Collapser c{bvh, out.pad, out};
+        auto root = c.emit(bvh.root_ref);
+        out.root_ref = root.first;
+        out.max_depth = root.second;
     }
     for (int a = 0; a < 3; ++a) {
-        out.root_lo[a] = round_down(rl[a] - pad);
-        out.root_hi[a] = round_up(rh[a] + pad);
+        out.root_lo[a] = round_down(rl[a] - out.pad);
+        out.root_hi[a] = round_up(rh[a] + out.pad);
     }
     return out;
 }

@@ -21,15 +21,18 @@ struct HostBvh {
 // complex_sphere.cpp:21-27, complex_cube.cpp:25-31, complex_plane.cpp:24-75).
 Box shape_bounds(const RtShape& s, double shutter_time);
 
-// FP32 image of the hierarchy for the device.  Every box is moved outward by an absolute pad that covers the rounding
-// of a ray origin to FP32 (|o| <= max_abs_coord, so |fl32(o) - o| <= 2^-24 max_abs_coord) and then rounded outward
-// to FP32; the relative rounding of the slab arithmetic itself is covered on the device (device_rt.h: box_test32).
-struct Bvh32 {
-    std::vector<DNode32> nodes;
+// Device image of the hierarchy: the binary tree collapsed to four children per node with 8-bit quantised child
+// boxes (device_types.h: DNode4).  Every box is first moved outward by an absolute pad that covers the FP32 rounding of
+// ray origins and of the device's slab arithmetic for coordinates up to max_abs_origin / the root box, then quantised
+// outward; relative rounding is covered on the device (device_rt.h: node4_test).
+struct Bvh4 {
+    std::vector<DNode4> nodes;     // node 0 = root (empty when the root is a leaf)
     float root_lo[3], root_hi[3];
     double pad = 0;
+    int32_t root_ref = 0;
+    int32_t max_depth = 0;         // 4-wide levels on the longest root->leaf path
 };
-Bvh32 to_node32(const HostBvh& bvh, double max_abs_origin);
+Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin);
 
 // What the device traverses: a binned-SAH hierarchy with single-primitive leaves over `boxes` (one per primitive,
 // indexed by the reference's depth-first order, so that leaf references are primitive indices).  At most max_depth

@@ -11,8 +11,8 @@
 namespace rt {
 
 // Megakernel schedule (render_mega.hip): renders this part's rows (params.part_rows rows of params.width pixels,
-// compact, tile order) into d_rgb8 with one launch on `stream`.  d_counters: NULL or 4 x u64 {rays, box tests,
-// primitive tests, reserved} that the kernel adds into.
+// compact, tile order) into d_rgb8 with one launch on `stream`.  d_counters: NULL or RT_N_COUNTERS x u64 {rays, box tests,
+// primitive tests, traversal ns (wavefront only), nodes fetched, ...} that the kernel adds into.
 hipError_t launch_render_mega(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
                               hipStream_t stream);
 
@@ -25,12 +25,10 @@ struct WavefrontWorkspace {
     double* accum = nullptr;             // FP64 RGB accumulator per pixel of the part
     size_t accum_pixels = 0;
     unsigned* counters = nullptr;        // [0] next ray to fetch, [1] rays emitted, [2] overflow flag
-    unsigned long long* stats = nullptr; // [1] box tests, [2] primitive tests
-    unsigned long long host_counts[4] = {0, 0, 0, 0};
-    std::vector<hipEvent_t> events;      // start/stop pairs around the k_traverse launches of the current frame
+    unsigned long long* stats = nullptr; // RT_N_COUNTERS entries: [1] box tests, [2] primitive tests, [4] nodes fetched
+    unsigned long long host_counts[RT_N_COUNTERS] = {};
+    std::vector<hipEvent_t> events;      // start/stop pairs around the k_traverse launches not yet collected
     size_t events_used = 0;
-    double last_traverse_ms = 0.0;       // summed k_traverse device time of the last frame whose counters were read
-    unsigned last_traverse_launches = 0;
     int compute_units = 256;
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);
@@ -39,5 +37,9 @@ void wavefront_workspace_free(WavefrontWorkspace& ws);
 // last queue has been drained (it reads queue sizes back between levels).
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
                                    hipStream_t stream, WavefrontWorkspace& ws);
+
+// Device time of the k_traverse launches enqueued through `ws` since the last collection (their stream must have been
+// synchronised: hipErrorNotReady otherwise), and how many launches that was.
+hipError_t wavefront_traverse_time(WavefrontWorkspace& ws, double* ms_out, unsigned* launches_out);
 
 }  // namespace rt

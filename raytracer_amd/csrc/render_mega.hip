@@ -20,7 +20,7 @@ constexpr int kBlock = 256;            // 4 waves; each wave owns an 8x8 pixel t
 // shading.h:42-75, the recursion through transparent occluders unrolled into a loop (each level multiplies the
 // running transmission by its own tint; the < 0.001 cut-off is applied to the level's own factor, as there).
 template <int F>
-__device__ D3 shadow_transmission(const DScene& S, const DParams& P, Ray sr, double dist, Counters& C, TravStack stack) {
+__device__ D3 shadow_transmission(const DScene& S, const DParams& P, Ray sr, double dist, Counters& C, TravStack& stack) {
     D3 total = mk(1.0, 1.0, 1.0);
     for (int seg = 0; seg < kShadowMaxSegments; ++seg) {
         Cand c;
@@ -49,7 +49,7 @@ __device__ D3 shadow_transmission(const DScene& S, const DParams& P, Ray sr, dou
 // shading.h:79-101
 template <int F>
 __device__ D3 light_visibility(const DScene& S, const DParams& P, const DLight& L, D3 Pt, D3 N, double time, Rng& rng, Counters& C,
-                               TravStack stack) {
+                               TravStack& stack) {
     if (!P.shadows) return mk(1.0, 1.0, 1.0);
     D3 acc = mk(0, 0, 0);
     for (int i = 0; i < P.shadow_samples; ++i) {
@@ -68,7 +68,7 @@ __device__ D3 light_visibility(const DScene& S, const DParams& P, const DLight& 
 // each, as the reference does.
 template <int F>
 __device__ void shade_local(const DScene& S, const DParams& P, const Hit& h, const Ray& view, Rng& rng, Counters& C,
-                            TravStack stack, D3& ad, D3& spec) {
+                            TravStack& stack, D3& ad, D3& spec) {
     const DMaterial& M = S.materials[h.material];
     D3 base;
     if (Feat<F>::tex && M.texture >= 0) {
@@ -127,7 +127,7 @@ struct Pending {   // one not-yet-traced ray of the Whitted tree: colour contrib
 // linear in the colours of its child rays, so each child carries the product of the weights above it and every
 // visited hit adds weight (x) local term to the pixel.
 template <int F>
-__device__ D3 trace(const DScene& S, const DParams& P, const Ray& primary, Rng& rng, Counters& C, TravStack tstack) {
+__device__ D3 trace(const DScene& S, const DParams& P, const Ray& primary, Rng& rng, Counters& C, TravStack& tstack) {
     Pending stack[kRayStackDepth];
     int sp = 0;
     D3 accum = mk(0, 0, 0);
@@ -224,8 +224,10 @@ __device__ D3 trace(const DScene& S, const DParams& P, const Ray& primary, Rng& 
 template <int F>
 __global__ void __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) k_render(const DScene S, const DParams P, uint8_t* __restrict__ out,
                                                    unsigned long long* __restrict__ counters) {
-    __shared__ int tstack_mem[kTravStackDepth][kBlock];
-    const TravStack tstack{&tstack_mem[0][threadIdx.x], kBlock};
+    __shared__ unsigned long long tstack_mem[kTravLdsEntries + 1][kBlock];   // + 1: discard row of push_sorted
+    TravStack tstack;
+    tstack.lds = &tstack_mem[0][threadIdx.x];
+    tstack.stride = kBlock;
 
     // XCD-aware block order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
     // L2); remap so that every XCD works on one contiguous run of image tiles and re-uses the BVH nodes it pulled in.
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) k_render(const DSce
     const int lr = by * 8 + (lane >> 3);   // row inside this part's compact slice
     const bool active = (x < P.width) && (lr < P.part_rows);
 
-    Counters C{0u, 0u, 0u};
+    Counters C{0u, 0u, 0u, 0u};
     if (active) {
         // compact row -> frame row: tile k of the slice is frame tile k*part_count + part_index
         const int y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
@@ -265,18 +267,20 @@ __global__ void __launch_bounds__(kBlock, RT_WAVES_PER_SIMD) k_render(const DSce
         o[2] = quantise(avg.z);
     }
     if (counters) {  // one atomic per wave and counter
-        unsigned int rays = C.rays, nodes = C.nodes, prims = C.prims;
+        unsigned int rays = C.rays, nodes = C.nodes, prims = C.prims, visits = C.visits;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);
             nodes += __shfl_down(nodes, off);
             prims += __shfl_down(prims, off);
+            visits += __shfl_down(visits, off);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], (unsigned long long)rays);
             if (P.count_tests) {
                 atomicAdd(&counters[1], (unsigned long long)nodes);
                 atomicAdd(&counters[2], (unsigned long long)prims);
+                atomicAdd(&counters[4], (unsigned long long)visits);
             }
         }
     }

@@ -31,6 +31,7 @@ namespace rt {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr unsigned kFetchCounterWords = 256;   // 8 XCD counters, 128 bytes apart (k_traverse)
 constexpr int kKindRadiance = 0, kKindShadow = 1;
 
 struct alignas(16) RayRec {
@@ -101,8 +102,11 @@ __device__ __forceinline__ void pixel_of(long long pix, int W, int rows, int& x,
     x = tx * 8 + rem % tw;
 }
 
-__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const Chunk ck, RayRec* __restrict__ out, long long n) {
+__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const Chunk ck, RayRec* __restrict__ out, long long n,
+                                                   unsigned* __restrict__ fetch_counters) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    // the traversal launched next on this stream starts with its queue fetch counters at zero (saves a memset launch)
+    if (blockIdx.x == 0 && threadIdx.x < kFetchCounterWords) fetch_counters[threadIdx.x] = 0u;
     if (i >= n) return;
     const long long pix = i / ck.ns;
     const int s = ck.s0 + (int)(i % ck.ns);
@@ -134,124 +138,178 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 #ifndef RT_NODE_VOTE
 #define RT_NODE_VOTE 24           // run an interior-node step while at least this many lanes want one
 #endif
+#ifndef RT_RAYS_PER_LANE
+#define RT_RAYS_PER_LANE 8        // the traversal grid shrinks until every lane has this many rays to work through
+#endif
+#ifndef RT_INNER_VOTE
+#define RT_INNER_VOTE 48          // stay in the node loop while at least this many lanes want another node
+#endif
+#ifndef RT_LEAF_VOTE
+#define RT_LEAF_VOTE 40           // test the parked leaves once this many lanes hold one
+#endif
+#ifndef RT_CHUNK
+#define RT_CHUNK 64               // rays a wave reserves from the queue per atomic
+#endif
 #ifndef RT_REFILL_VOTE
-#define RT_REFILL_VOTE 16         // fetch new rays once this many lanes are idle
+#define RT_REFILL_VOTE 8          // fetch new rays once this many lanes are idle
 #endif
 
-template <int F>
+// The queue is cut into one contiguous share per XCD, each with its own fetch counter (on its own cache line): the
+// waves of an XCD work through neighbouring rays, so that the part of the hierarchy they touch stays in that XCD's
+// 4 MB L2, and take from the other shares only once their own is empty.
+constexpr unsigned kXcds = 8;
+constexpr unsigned kNextStride = kFetchCounterWords / kXcds;   // counters 128 bytes apart
+constexpr unsigned kNextBase = 32;     // offset of the fetch counters in WavefrontWorkspace::counters
+__device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
+    return q >= kXcds ? n : (unsigned)(((unsigned long long)n * q / kXcds) & ~63ull);
+}
+
+// COUNT: also count box tests / node fetches / primitive tests (the statistics pass of bench.py and RtStats); the
+// timed variant carries neither the registers nor the instructions for them.
+template <int F, bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_TRAVERSE_WAVES)
 k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, HitRec* __restrict__ hits, const unsigned n,
            unsigned* __restrict__ next, unsigned long long* __restrict__ counters) {
-    __shared__ int stack_mem[kTravStackDepth][kBlock];
-    const TravStack stack{&stack_mem[0][threadIdx.x], kBlock};
+    __shared__ unsigned long long stack_mem[kTravLdsEntries + 1][kBlock];   // + 1: the row branch-free pushes discard into
+    TravStack stack;
+    stack.lds = &stack_mem[0][threadIdx.x];
+    stack.stride = kBlock;
     const int lane = threadIdx.x & 63;
     constexpr int kDone = 0x7fffffff;
+    constexpr unsigned kNone = 0xffffffffu;
 
-    bool active = false, exhausted = false;
-    unsigned my = 0;
+    bool exhausted = false;
+    unsigned my = kNone;                               // queue index of this lane's ray; kNone = idle lane
+    unsigned chunk_next = 0, chunk_end = 0;            // this wave's reserved rays [chunk_next, chunk_end)
+    const unsigned xcd = blockIdx.x & (kXcds - 1u);     // workgroups are dealt to the XCDs round-robin
+    unsigned victim = 0;                               // shares of the queue found empty so far
     Ray r{mk(0, 0, 0), mk(0, 0, 1), 0.0};
-    RayF rf{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    RayF rf{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0u, 0u, 0u}};
     double tmin = 0.0;
-    float tmin32 = 0.f;
+    float tmin32 = 0.f, tmax32 = 0.f;   // tmax32 follows best.t (rounded up)
     Cand best{0.0, -1, 0, 0.0, 0.0};
-    int best_order = 0, sp = 0, cur = kDone;
+    int best_order = 0, sp = 0, cur = kDone, pend = 0;   // pend: parked leaf reference (< 0) or 0; idle: cur == kDone, pend == 0
     bool best_incl = false;
-    Counters C{0u, 0u, 0u};
+    Counters C{0u, 0u, 0u, 0u};
+    unsigned ray_visits = 0, max_visits = 0, iters = 0;   // statistics (COUNT only)
 
     while (true) {
-        // ---- refill idle lanes with the next rays of the queue
-        const unsigned long long idle = __ballot(!active);
+        if (COUNT) ++iters;
+        // ---- refill idle lanes with the next rays of the queue.  A wave reserves RT_CHUNK consecutive rays with one
+        //      atomic and hands them to its lanes as they fall idle (one atomic per refill on a single counter serialises
+        //      in L2 and was the bottleneck of the whole kernel).
+        const unsigned long long idle = __ballot(my == kNone);
         if (!exhausted && idle != 0ull && (__popcll(idle) >= RT_REFILL_VOTE || idle == ~0ull)) {
-            const int cnt = __popcll(idle);
-            const int leader = __ffsll((long long)idle) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(next, (unsigned)cnt);
-            base = __shfl(base, leader);
-            if (base + (unsigned)cnt >= n) exhausted = true;
-            if (!active) {
-                my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                if (my < n) {
-                    const RayRec q = rays[my];
-                    r.o = ld3(q.o);
-                    r.d = ld3(q.d);
-                    r.time = q.time;
-                    const bool shadow = q.kind == kKindShadow;
-                    tmin = shadow ? 0.001 : P.eps_scene;                       // shading.h:45 / tracer.h:152-156
-                    const double tmax = shadow ? q.tmax - 0.001 : q.tmax;
-                    best = Cand{tmax, -1, 0, 0.0, 0.0};
-                    best_order = 0;
-                    best_incl = false;
-                    sp = 0;
-                    cur = kDone;
-                    active = true;
-                    if (S.n_prims > 0) {
-                        if (P.use_bvh) {
-                            rf = make_rayf(r);
-                            tmin32 = __double2float_rd(tmin);
-                            float e;
-                            if (P.count_tests) C.nodes++;
-                            if (box_test32(S.root_lo, S.root_hi, rf, tmin32, __double2float_ru(tmax), e)) cur = S.root_ref;
-                        } else {  // --no-bvh: the list in scene-file order (hittable_list.cpp:8-33)
-                            for (int i = 0; i < S.n_prims; ++i) test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
-                        }
+            while (chunk_next >= chunk_end) {   // wave-uniform: this XCD's share of the queue first, then the others'
+                const unsigned qx = (xcd + victim) & (kXcds - 1u);
+                const unsigned lo = share_begin(n, qx), hi = share_begin(n, qx + 1u);
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&next[qx * kNextStride], (unsigned)RT_CHUNK);
+                base = __shfl(base, 0);
+                if (base < hi - lo) {
+                    chunk_next = lo + base;
+                    chunk_end = (hi - lo - base < (unsigned)RT_CHUNK) ? hi : chunk_next + (unsigned)RT_CHUNK;
+                } else if (++victim == kXcds) {
+                    exhausted = true;
+                    break;
+                }
+            }
+            const unsigned avail = chunk_end - chunk_next;
+            const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+            const unsigned take = min((unsigned)__popcll(idle), avail);
+            if (my == kNone && rank < take) {
+                my = chunk_next + rank;
+                const RayRec q = rays[my];
+                r.o = ld3(q.o);
+                r.d = ld3(q.d);
+                r.time = q.time;
+                const bool shadow = q.kind == kKindShadow;
+                tmin = shadow ? 0.001 : P.eps_scene;                       // shading.h:45 / tracer.h:152-156
+                const double tmax = shadow ? q.tmax - 0.001 : q.tmax;
+                best = Cand{tmax, -1, 0, 0.0, 0.0};
+                best_order = 0;
+                best_incl = false;
+                sp = 0;
+                cur = kDone;
+                pend = 0;
+                if (S.n_prims > 0) {
+                    if (P.use_bvh) {
+                        rf = make_rayf(r);
+                        tmin32 = __double2float_rd(tmin);
+                        float e;
+                        if (COUNT) C.nodes++;
+                        tmax32 = __double2float_ru(tmax);
+                        if (box_test32(S.root_lo, S.root_hi, rf, tmin32, tmax32, e)) cur = S.root_ref;
+                    } else {  // --no-bvh: the list in scene-file order (hittable_list.cpp:8-33)
+                        for (int i = 0; i < S.n_prims; ++i) test_prim<F, COUNT>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
                     }
                 }
             }
+            chunk_next += take;
         }
-        if (__ballot(active) == 0ull) {
+        if (__ballot(my != kNone) == 0ull) {
             if (exhausted) break;
             continue;
         }
-        // ---- one step for the wave: interior nodes while enough lanes want them, otherwise the pending leaves
-        const bool is_node = active && static_cast<unsigned>(cur) < static_cast<unsigned>(kDone);
-        const bool is_leaf = active && cur < 0;
-        const unsigned long long mn = __ballot(is_node), ml = __ballot(is_leaf);
-        if (mn != 0ull && (__popcll(mn) >= RT_NODE_VOTE || ml == 0ull)) {
-            if (is_node) {
-                const NodeRegs nd = load_node(&S.nodes[cur]);
-                if (P.count_tests) C.nodes += 2;
-                float e0, e1;
-                const float tmax32 = __double2float_ru(best.t);
-                const bool h0 = box_test32(nd.lo[0], nd.hi[0], rf, tmin32, tmax32, e0);
-                const bool h1 = box_test32(nd.lo[1], nd.hi[1], rf, tmin32, tmax32, e1);
-                const int c0 = nd.child[0], c1 = nd.child[1];
-                if (h0 && h1) {
-                    const bool left_first = !(e1 < e0);
-                    stack.at(sp++) = left_first ? c1 : c0;
-                    cur = left_first ? c0 : c1;
-                } else if (h0) {
-                    cur = c0;
-                } else if (h1) {
-                    cur = c1;
-                } else {
-                    cur = sp ? stack.at(--sp) : kDone;
+        // ---- a lane that reached a leaf parks it (one slot) and goes on with its next deferred node, so that node steps
+        //      keep their lanes and the FP64 primitive tests run for many lanes at once.  The parked leaf may shorten
+        //      the ray later than in a strict traversal, which only costs node visits, never a hit.
+        if (cur < 0 && pend == 0) {
+            pend = cur;
+            cur = stack.pop(sp, tmax32);
+        }
+        bool is_node = static_cast<unsigned>(cur) < static_cast<unsigned>(kDone);
+        int nn = __popcll(__ballot(is_node));
+        const int nl = __popcll(__ballot(pend != 0));
+        if (nn != 0 && nl < RT_LEAF_VOTE && (nn >= RT_NODE_VOTE || nn >= nl)) {
+            // ---- interior nodes; while most of the wave still wants one, stay here (no scheduling work per step)
+            do {
+                if (is_node) {
+                    const NodeRegs nd = load_node(&S.nodes[cur]);
+                    if (COUNT) { C.nodes += node4_children(nd); C.visits++; ray_visits++; }
+                    cur = node4_step(nd, rf, tmin32, tmax32, stack, sp);
+                    if (cur < 0 && pend == 0) {
+                        pend = cur;
+                        cur = stack.pop(sp, tmax32);
+                    }
                 }
-            }
-        } else if (ml != 0ull) {
-            if (is_leaf) {
-                const int code = ~cur;
+                is_node = static_cast<unsigned>(cur) < static_cast<unsigned>(kDone);
+                nn = __popcll(__ballot(is_node));
+                if (COUNT) ++iters;
+            } while (nn >= RT_INNER_VOTE);
+        } else if (nl != 0) {
+            // ---- the parked leaves
+            if (pend != 0) {
+                const int code = ~pend;
                 const int first = code >> 1;
-                test_prim<F>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
-                if (code & 1) test_prim<F>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
-                cur = sp ? stack.at(--sp) : kDone;
+                test_prim<F, COUNT>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
+                if (code & 1) test_prim<F, COUNT>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+                tmax32 = __double2float_ru(best.t);
+                pend = 0;
             }
         }
         // ---- retire finished rays
-        if (active && cur == kDone) {
+        if (my != kNone && cur == kDone && pend == 0) {
             HitRec h;
             h.t = best.t; h.bu = best.bu; h.bv = best.bv; h.prim = best.prim; h.tri = best.tri;
             hits[my] = h;
-            active = false;
+            my = kNone;
+            if (COUNT) { max_visits = max(max_visits, ray_visits); ray_visits = 0; }
         }
     }
-    if (counters && P.count_tests) {
-        unsigned nodes = C.nodes, prims = C.prims;
+    if (COUNT && counters) {
+        unsigned nodes = C.nodes, prims = C.prims, visits = C.visits;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             nodes += __shfl_down(nodes, off);
             prims += __shfl_down(prims, off);
+            visits += __shfl_down(visits, off);
+            max_visits = max(max_visits, (unsigned)__shfl_down(max_visits, off));
         }
         if (lane == 0) {
+            atomicMax(&counters[5], (unsigned long long)max_visits);
+            atomicMax(&counters[6], (unsigned long long)iters);
+            atomicAdd(&counters[4], (unsigned long long)visits);
             atomicAdd(&counters[1], (unsigned long long)nodes);
             atomicAdd(&counters[2], (unsigned long long)prims);
         }
@@ -449,14 +507,21 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ a
 }
 
 __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, unsigned long long boxes, unsigned long long prims,
-                               unsigned long long traverse_ns) {
-    if (threadIdx.x == 0) { c[0] += rays; c[1] += boxes; c[2] += prims; c[3] += traverse_ns; }
+                               unsigned long long traverse_ns, unsigned long long fetches, unsigned long long max_fetches,
+                               unsigned long long max_iters) {
+    if (threadIdx.x == 0) {
+        c[0] += rays; c[1] += boxes; c[2] += prims; c[3] += traverse_ns; c[4] += fetches;
+        if (max_fetches > c[5]) c[5] = max_fetches;
+        if (max_iters > c[6]) c[6] = max_iters;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host driver
 constexpr int kSpheres = RT_FEAT_SPHERE;
 constexpr int kAnalytic = RT_FEAT_SPHERE | RT_FEAT_QUAD | RT_FEAT_CUBE;
 constexpr int kFull = kAnalytic | RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV;
+
+constexpr size_t kMaxTimedEvents = 8192;   // start/stop events kept per workspace until they are collected
 
 struct Driver {
     const DScene& S;
@@ -466,6 +531,7 @@ struct Driver {
     int variant;
     int traverse_blocks;
     unsigned long long rays_traced = 0;
+    bool may_emit = true;   // false: no launch of k_shade can queue a ray
     hipError_t err = hipSuccess;
 
     bool ok(hipError_t e) {
@@ -497,6 +563,7 @@ struct Driver {
     }
 
     hipEvent_t next_event() {
+        if (ws.events_used >= kMaxTimedEvents) return nullptr;
         if (ws.events_used == ws.events.size()) {
             hipEvent_t e = nullptr;
             if (!ok(hipEventCreate(&e))) return nullptr;
@@ -505,17 +572,27 @@ struct Driver {
         return ws.events[ws.events_used++];
     }
     template <int F> void launch_traverse(int q, unsigned n) {
-        hipEvent_t e0 = next_event(), e1 = next_event();
-        if (e0) (void)hipEventRecord(e0, stream);
+        const bool timed = ws.events_used + 2 <= kMaxTimedEvents;
+        hipEvent_t e0 = timed ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
+        if (e1) (void)hipEventRecord(e0, stream);
         launch_traverse_kernel<F>(q, n);
         if (e1) (void)hipEventRecord(e1, stream);
+        else if (e0) --ws.events_used;   // keep start/stop pairs whole
     }
     template <int F> void launch_traverse_kernel(int q, unsigned n) {
-        hipLaunchKernelGGL(k_traverse<F>, dim3(traverse_blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, ws.counters + 0,
-                           ws.stats);
+        // Persistent grid sized by the work: at least RT_RAYS_PER_LANE rays per lane, so that lanes can be refilled and
+        // a small queue (a part of a frame, a deep level of the ray tree) leaves the other CUs to concurrent streams.
+        const unsigned want = (n + kBlock * RT_RAYS_PER_LANE - 1) / (kBlock * RT_RAYS_PER_LANE);
+        const unsigned blocks = std::max(1u, std::min((unsigned)traverse_blocks, want));
+        if (P.count_tests)
+            hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n,
+                               ws.counters + kNextBase, ws.stats);
+        else
+            hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n,
+                               ws.counters + kNextBase, ws.stats);
     }
     template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo) {
-        EmitCtx E{rays(qo), ws.counters + 1, ws.counters + 2, (unsigned)ws.capacity};
+        EmitCtx E{qo >= 0 ? rays(qo) : nullptr, ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u};
         hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q) + start, hits(q) + start, n,
                            E, ws.accum);
     }
@@ -523,11 +600,19 @@ struct Driver {
     // Trace and shade the n rays of queue q (owned by this call, released when fully consumed), then their children.
     void process(int q, unsigned n, int level) {
         if (err != hipSuccess || n == 0) { release(q); return; }
-        if (!ok(hipMemsetAsync(ws.counters, 0, sizeof(unsigned), stream))) { release(q); return; }
+        // level 0: k_raygen has zeroed the fetch counters
+        if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) { release(q); return; }
         if (variant == 0) launch_traverse<kSpheres>(q, n);
         else if (variant == 1) launch_traverse<kAnalytic>(q, n);
         else launch_traverse<kFull>(q, n);
         rays_traced += n;
+        if (!may_emit) {   // no material spawns rays and shadows are off: shade and return, nothing to read back (asynchronous)
+            if (variant == 0) launch_shade<kSpheres>(q, 0, n, -1);
+            else if (variant == 1) launch_shade<kAnalytic>(q, 0, n, -1);
+            else launch_shade<kFull>(q, 0, n, -1);
+            release(q);
+            return;
+        }
         const size_t fo = fanout(level);
         const unsigned batch = (unsigned)std::max<size_t>(1, std::min<size_t>(n, ws.capacity / fo));
         for (unsigned start = 0; start < n && err == hipSuccess; start += batch) {
@@ -572,8 +657,8 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         const char* env = getenv("RT_QUEUE_RAYS");
         size_t cap = env ? strtoull(env, nullptr, 10) : 0;
         ws.capacity = cap >= 4096 ? cap : (size_t(1) << 24);
-        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), 16 * sizeof(unsigned))) != hipSuccess) return e;
-        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), 4 * sizeof(unsigned long long))) != hipSuccess) return e;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), (kNextBase + kXcds * kNextStride) * sizeof(unsigned))) != hipSuccess) return e;
+        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return e;
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -587,10 +672,12 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         ws.accum_pixels = npix;
     }
     if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(ws.stats, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
 
-    ws.events_used = 0;
+    if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
+    const size_t first_event = ws.events_used;
     Driver D{scene, params, ws, stream, 0, 0};
+    D.may_emit = !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
     const int f = scene.features;
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
     // persistent traversal grid: every CU gets RT_TRAVERSE_WAVES waves per SIMD (LDS: 24 KB per 256-thread block)
@@ -611,28 +698,49 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             const long long n = (long long)rows * W * ck.ns;
             const int q = D.acquire();
             if (q < 0) break;
-            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n);
+            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
+                               ws.counters + kNextBase);
             D.process(q, (unsigned)n, 0);
         }
     }
     if (D.err != hipSuccess) return D.err;
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
                        params.spp, params.tonemap);
-    if (d_counters) {  // rays are counted on the host (every traversed queue entry is one closest-hit query)
+    // Rays are counted on the host (every traversed queue entry is one closest-hit query).  With count_tests the call
+    // also waits for the frame, reads the test counters and the traversal time of this frame's launches; without, it
+    // stays asynchronous and the traversal time is collected later (wavefront_traverse_time).
+    if (d_counters && params.count_tests) {
         ws.host_counts[0] = D.rays_traced;
-        if ((e = hipMemcpyAsync(ws.host_counts + 1, ws.stats + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(ws.host_counts + 1, ws.stats + 1, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
         double ms = 0.0;
-        for (size_t i = 0; i + 1 < ws.events_used; i += 2) {
+        for (size_t i = first_event; i + 1 < ws.events_used; i += 2) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, ws.events[i], ws.events[i + 1]) == hipSuccess) ms += t;
         }
-        ws.last_traverse_ms = ms;
-        ws.last_traverse_launches = (unsigned)(ws.events_used / 2);
+        ws.events_used = first_event;
         hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, ws.host_counts[0], ws.host_counts[1], ws.host_counts[2],
-                           (unsigned long long)(ms * 1e6));
+                           (unsigned long long)(ms * 1e6), ws.host_counts[4], ws.host_counts[5], ws.host_counts[6]);
+    } else if (d_counters) {
+        hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, D.rays_traced, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull);
     }
     return hipGetLastError();
+}
+
+hipError_t wavefront_traverse_time(WavefrontWorkspace& ws, double* ms_out, unsigned* launches_out) {
+    double ms = 0.0;
+    unsigned launches = 0;
+    for (size_t i = 0; i + 1 < ws.events_used; i += 2) {
+        float t = 0.f;
+        hipError_t e = hipEventElapsedTime(&t, ws.events[i], ws.events[i + 1]);
+        if (e != hipSuccess) return e;   // hipErrorNotReady: the stream has not been synchronised
+        ms += t;
+        ++launches;
+    }
+    ws.events_used = 0;
+    *ms_out = ms;
+    *launches_out = launches;
+    return hipSuccess;
 }
 
 }  // namespace rt

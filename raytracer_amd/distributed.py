@@ -36,11 +36,13 @@ class FrameGather:
         self.width, self.height, self.tile_rows = width, height, tile_rows
         self.max_rows = max_part_rows(height, tile_rows, self.world)
         self.slice = torch.zeros((self.max_rows, width, 3), dtype=torch.uint8, device=device)
-        self.gathered, self.frame, self.index = None, None, None
+        self.gathered, self.gather_buffer, self.frame, self.index = None, None, None, None
         if self.rank == 0:
             self.frame = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
             if self.world > 1:
-                self.gathered = [torch.empty_like(self.slice) for _ in range(self.world)]
+                # one contiguous buffer, gathered into through per-rank views: de-interleaving reads it in place
+                self.gather_buffer = torch.empty((self.world * self.max_rows, width, 3), dtype=torch.uint8, device=device)
+                self.gathered = list(self.gather_buffer.view(self.world, self.max_rows, width, 3).unbind(0))
                 self.index = torch.from_numpy(deinterleave_index(height, tile_rows, self.world, self.max_rows)).to(device)
 
     def run(self):
@@ -49,6 +51,6 @@ class FrameGather:
             return self.slice[: self.height]
         dist.gather(self.slice, self.gathered, dst=0)
         if self.rank == 0:
-            torch.index_select(torch.cat(self.gathered, 0), 0, self.index, out=self.frame)
+            torch.index_select(self.gather_buffer, 0, self.index, out=self.frame)
             return self.frame
         return None
