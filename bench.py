@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile-rows", type=int, default=8)
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=8,
                     help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the same frame")

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 #define RT_NODE_VOTE 24           // run an interior-node step while at least this many lanes want one
 #endif
 #ifndef RT_RAYS_PER_LANE
-#define RT_RAYS_PER_LANE 8        // the traversal grid shrinks until every lane has this many rays to work through
+#define RT_RAYS_PER_LANE 2        // the traversal grid shrinks until every lane has this many rays to work through
 #endif
 #ifndef RT_INNER_VOTE
 #define RT_INNER_VOTE 48          // stay in the node loop while at least this many lanes want another node
@@ -322,7 +322,22 @@ struct EmitCtx {
     unsigned* count;
     unsigned* overflow;
     unsigned cap;
+    uint8_t* direct;   // non-null: one ray per pixel and no children (1 spp, nothing spawns rays): the colour of a ray is
+                       // the pixel, written tone-mapped straight into the frame instead of summed and resolved later
 };
+
+// Contribution c of one ray to its pixel.
+__device__ __forceinline__ void deposit(const EmitCtx& E, const DParams& P, double* accum, int pixel, D3 c) {
+    if (E.direct) {
+        const D3 m = tonemap(c, P.tonemap);   // == k_resolve with spp 1 (main.cpp:308-316)
+        uint8_t* o = E.direct + (size_t)pixel * 3;
+        o[0] = quantise(m.x);
+        o[1] = quantise(m.y);
+        o[2] = quantise(m.z);
+    } else {
+        accum_add(accum, pixel, c);
+    }
+}
 
 template <int F>
 __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayRec* __restrict__ rays,
@@ -339,7 +354,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
 
     if (q.kind == kKindShadow) {  // shading.h:42-75, one segment of the transmission chain
         if (c.prim < 0) {  // reached the light sample: this sample's share of the light term
-            accum_add(accum, q.pixel, w);
+            deposit(E, P, accum, q.pixel, w);
             return;
         }
         const DPrim pr = S.prims[c.prim];
@@ -365,13 +380,13 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
     // ---- radiance ray: tracer.h:147-295
     if (c.prim < 0) {
         D3 bg = (Feat<F>::env && S.env_present) ? env_sample(S, r.d) : ld3(P.background);  // tracer.h:282-293
-        accum_add(accum, q.pixel, cmul(w, bg));
+        deposit(E, P, accum, q.pixel, cmul(w, bg));
         return;
     }
     Hit h;
     fill_hit<F>(S, P, r, c, h);
     if (P.normals) {  // tracer.h:157-161
-        accum_add(accum, q.pixel, cmul(w, (h.n + mk(1, 1, 1)) * 0.5));
+        deposit(E, P, accum, q.pixel, cmul(w, (h.n + mk(1, 1, 1)) * 0.5));
         return;
     }
     const DMaterial& M = S.materials[h.material];
@@ -460,7 +475,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
             }
         }
     }
-    accum_add(accum, q.pixel, cmul(w, ad * ad_weight + spec));
+    deposit(E, P, accum, q.pixel, cmul(w, ad * ad_weight + spec));
 
     // ---- secondary rays
     const int child_depth = q.depth - 1;
@@ -532,6 +547,7 @@ struct Driver {
     int traverse_blocks;
     unsigned long long rays_traced = 0;
     bool may_emit = true;   // false: no launch of k_shade can queue a ray
+    uint8_t* direct = nullptr;   // see EmitCtx::direct
     hipError_t err = hipSuccess;
 
     bool ok(hipError_t e) {
@@ -592,7 +608,7 @@ struct Driver {
                                ws.counters + kNextBase, ws.stats);
     }
     template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo) {
-        EmitCtx E{qo >= 0 ? rays(qo) : nullptr, ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u};
+        EmitCtx E{qo >= 0 ? rays(qo) : nullptr, ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
         hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q) + start, hits(q) + start, n,
                            E, ws.accum);
     }
@@ -671,13 +687,14 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         if ((e = hipMalloc(reinterpret_cast<void**>(&ws.accum), npix * 3 * sizeof(double))) != hipSuccess) return e;
         ws.accum_pixels = npix;
     }
-    if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
 
     if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
     const size_t first_event = ws.events_used;
     Driver D{scene, params, ws, stream, 0, 0};
     D.may_emit = !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
+    if (!D.may_emit && params.spp == 1) D.direct = d_rgb8;
+    else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
     // persistent traversal grid: every CU gets RT_TRAVERSE_WAVES waves per SIMD (LDS: 24 KB per 256-thread block)
@@ -704,8 +721,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         }
     }
     if (D.err != hipSuccess) return D.err;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
-                       params.spp, params.tonemap);
+    if (!D.direct)
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
+                           params.spp, params.tonemap);
     // Rays are counted on the host (every traversed queue entry is one closest-hit query).  With count_tests the call
     // also waits for the frame, reads the test counters and the traversal time of this frame's launches; without, it
     // stays asynchronous and the traversal time is collected later (wavefront_traverse_time).
