@@ -8,7 +8,9 @@ in the HIP kernels inside the shared library; there is no Python or CPU renderin
 module fails loudly when the library has not been built.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -114,10 +116,32 @@ ABI_SYMBOLS = [
 ]
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels ship their own libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's).  If this
+    library is loaded first it binds /opt/rocm's copy, a later `import torch` maps its own, and a process with two HIP
+    runtimes cannot share streams or buffers (torch then reports "No HIP GPUs are available").  Mapping torch's copy
+    first makes both use one runtime whichever is imported first.  Without torch installed nothing happens."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("librt_mi355x.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C raytracer_amd/csrc`); raytracer_amd has no fallback path")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, dbl, cp = C.c_void_p, C.c_int, C.c_double, C.c_char_p
     sig = {

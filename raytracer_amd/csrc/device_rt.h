@@ -517,11 +517,11 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
     }
 }
 
-// Slab test of aabb.cpp:4-38 in FP32 on the widened boxes of DNode32.  It only has to be CONSERVATIVE: whenever the
+// Slab test of aabb.cpp:4-38 in FP32 on a widened box (the root box; the node boxes use node4_test below).  It only has to be CONSERVATIVE: whenever the
 // reference's FP64 test (running tmin/tmax over the three axes, reject on tmax <= tmin) accepts, this one accepts.
 //   * the box was moved outward on the host by more than the FP32 rounding of the ray origin;
 //   * every FP32 operation below has relative error <= 2^-24, so entry distances are lowered and exit distances
-//     raised by 2^-21 relative before they are compared;
+//     raised by 2^-20 relative before they are compared (the reciprocal of the direction carries up to 1.5 * 2^-23);
 //   * tmin is rounded down and tmax up when converted;
 //   * a NaN (inf - inf on an axis-parallel ray) is ignored by fmaxf/fminf, which can only widen the interval.
 // The reference leaves its axis loop at the first failing axis; since tmin only grows and tmax only shrinks that is
@@ -533,7 +533,9 @@ struct RayF {
 };
 __device__ __forceinline__ RayF make_rayf(const Ray& r) {
     RayF f;
-    f.inv[0] = (float)(1.0 / r.d.x); f.inv[1] = (float)(1.0 / r.d.y); f.inv[2] = (float)(1.0 / r.d.z);
+    // FP32 reciprocal of the direction rounded to FP32 (v_rcp_f32, 1 ulp): relative error under 1.5 * 2^-23, which
+    // scales every slab distance alike and is part of the relative slack of the box tests below.
+    f.inv[0] = __builtin_amdgcn_rcpf((float)r.d.x); f.inv[1] = __builtin_amdgcn_rcpf((float)r.d.y); f.inv[2] = __builtin_amdgcn_rcpf((float)r.d.z);
     f.oi[0] = (float)r.o.x * f.inv[0]; f.oi[1] = (float)r.o.y * f.inv[1]; f.oi[2] = (float)r.o.z * f.inv[2];
     f.neg[0] = f.inv[0] < 0.f ? ~0u : 0u; f.neg[1] = f.inv[1] < 0.f ? ~0u : 0u; f.neg[2] = f.inv[2] < 0.f ? ~0u : 0u;
     return f;
@@ -542,7 +544,7 @@ __device__ __forceinline__ RayF make_rayf(const Ray& r) {
 // rounding, which the host pad covers four times over.  min/max order the two planes of an axis (no sign select).
 // For an exactly axis-parallel ray (inv = +-inf) both products are NaN and the axis simply does not constrain.
 __device__ __forceinline__ bool box_test32(const float* lo, const float* hi, const RayF& f, float tmin, float tmax, float& entry) {
-    constexpr float kSlack = 4.76837158e-7f;  // 2^-21
+    constexpr float kSlack = 9.53674316e-7f;  // 2^-20
     const float ax = fmaf(lo[0], f.inv[0], -f.oi[0]), bx = fmaf(hi[0], f.inv[0], -f.oi[0]);
     const float ay = fmaf(lo[1], f.inv[1], -f.oi[1]), by = fmaf(hi[1], f.inv[1], -f.oi[1]);
     const float az = fmaf(lo[2], f.inv[2], -f.oi[2]), bz = fmaf(hi[2], f.inv[2], -f.oi[2]);
@@ -583,7 +585,7 @@ __device__ __forceinline__ NodeRegs load_node(const DNode4* n) {
 // NaNs of axis-parallel rays drop out of min3/max3).  e[c] = entry distance of child c, +inf when missed/unused.
 typedef float rt_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, float tmin, float tmax, float e[4]) {
-    constexpr float kSlack = 4.76837158e-7f;  // 2^-21
+    constexpr float kSlack = 9.53674316e-7f;  // 2^-20
     rt_f2 a[3], b[3];
     unsigned qn[3], qf[3];
 #pragma unroll

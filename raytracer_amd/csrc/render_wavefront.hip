@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 #define RT_INNER_VOTE 48          // stay in the node loop while at least this many lanes want another node
 #endif
 #ifndef RT_LEAF_VOTE
-#define RT_LEAF_VOTE 40           // test the parked leaves once this many lanes hold one
+#define RT_LEAF_VOTE 8            // test the parked leaves once this many lanes hold one
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64               // rays a wave reserves from the queue per atomic

@@ -17,6 +17,7 @@ def _render_on_streams(scene, params, n_streams, rounds, shape):
     dev = torch.device("cuda", 0)
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     bufs = [torch.zeros(shape, dtype=torch.uint8, device=dev) for _ in range(n_streams)]
+    torch.cuda.synchronize(dev)   # the fills ran on torch's default stream; the renders below do not wait for it
     for _ in range(rounds):
         for s, b in zip(streams, bufs):
             scene.render_device(params, b.data_ptr(), stream=s.cuda_stream)
