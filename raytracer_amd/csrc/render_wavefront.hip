@@ -339,14 +339,10 @@ __device__ __forceinline__ void deposit(const EmitCtx& E, const DParams& P, doub
     }
 }
 
+// Shades one traced ray: returns whether it contributes `contrib` to its pixel, and queues its child rays.
 template <int F>
-__global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayRec* __restrict__ rays,
-                                                  const HitRec* __restrict__ hits, const unsigned n, const EmitCtx E,
-                                                  double* __restrict__ accum) {
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const RayRec q = rays[i];
-    const HitRec hr = hits[i];
+__device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, const RayRec& q, const HitRec& hr, const EmitCtx& E,
+                                          D3& contrib) {
     const Ray r{ld3(q.o), ld3(q.d), q.time};
     const D3 w = ld3(q.w);
     Rng rng{q.rng, P.rng_mode == RT_RNG_D0};
@@ -354,40 +350,40 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
 
     if (q.kind == kKindShadow) {  // shading.h:42-75, one segment of the transmission chain
         if (c.prim < 0) {  // reached the light sample: this sample's share of the light term
-            deposit(E, P, accum, q.pixel, w);
-            return;
+            contrib = w;
+            return true;
         }
         const DPrim pr = S.prims[c.prim];
         const DMaterial& M = S.materials[pr.material];
-        if (!(M.transparency > 0.0)) return;  // opaque occluder: transmission 0
+        if (!(M.transparency > 0.0)) return false;  // opaque occluder: transmission 0
         Hit h;
         fill_hit<F>(S, P, r, c, h);
         double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
         double eta = n1 / n2;
         double cos_i = -dot(r.d, h.n);
         double sin2 = eta * eta * (1.0 - cos_i * cos_i);
-        if (sin2 > 1.0) return;
+        if (sin2 > 1.0) return false;
         double r0 = ((n1 - n2) / (n1 + n2));
         r0 = r0 * r0;
         double refl = r0 + (1.0 - r0) * pow((1.0 - cos_i), 5.0);  // shadow_schlick, shading.h:24-28
         D3 local = cmul(mk(1.0, 1.0, 1.0), ld3(M.diffuse)) * (1.0 - refl);
-        if (length(local) < 0.001) return;
+        if (length(local) < 0.001) return false;
         emit_ray(E.out, E.count, E.cap, E.overflow, h.p + r.d * 0.001, r.d, cmul(w, local), q.time, q.tmax - h.t, rng.next(), q.pixel,
                  q.depth, kKindShadow);
-        return;
+        return false;
     }
 
     // ---- radiance ray: tracer.h:147-295
     if (c.prim < 0) {
         D3 bg = (Feat<F>::env && S.env_present) ? env_sample(S, r.d) : ld3(P.background);  // tracer.h:282-293
-        deposit(E, P, accum, q.pixel, cmul(w, bg));
-        return;
+        contrib = cmul(w, bg);
+        return true;
     }
     Hit h;
     fill_hit<F>(S, P, r, c, h);
     if (P.normals) {  // tracer.h:157-161
-        deposit(E, P, accum, q.pixel, cmul(w, (h.n + mk(1, 1, 1)) * 0.5));
-        return;
+        contrib = cmul(w, (h.n + mk(1, 1, 1)) * 0.5);
+        return true;
     }
     const DMaterial& M = S.materials[h.material];
     const bool transparent = M.transparency > 0;
@@ -475,11 +471,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
             }
         }
     }
-    deposit(E, P, accum, q.pixel, cmul(w, ad * ad_weight + spec));
+    contrib = cmul(w, ad * ad_weight + spec);
 
     // ---- secondary rays
     const int child_depth = q.depth - 1;
-    if (child_depth <= 0) return;  // children would return black without tracing (tracer.h:149)
+    if (child_depth <= 0) return true;  // children would return black without tracing (tracer.h:149)
     if (has_refl) {  // tracer.h:176-219
         int samples = P.glossy_samples;
         if (q.depth < P.max_bounces) samples = 1;
@@ -507,6 +503,45 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
     if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
         emit_ray(E.out, E.count, E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time, 100000.0,
                  rng.next(), q.pixel, child_depth, kKindRadiance);
+    return true;
+}
+
+// One lane per traced ray.  Contributions go to the FP64 accumulators with atomics, which on this chip execute at the
+// memory side at a fraction of the store rate (MI355X_MICROARCH.md, global float atomics), so lanes that follow each
+// other with the same pixel -- the samples of one pixel and their children stay neighbours in the queues -- are summed
+// inside the wave first and only the first lane of each run issues the three atomics.
+template <int F>
+__global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayRec* __restrict__ rays,
+                                                  const HitRec* __restrict__ hits, const unsigned n, const EmitCtx E,
+                                                  double* __restrict__ accum) {
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    D3 c = mk(0.0, 0.0, 0.0);
+    int pixel = -1 - lane;   // lanes without a contribution: a run of their own
+    if (i < n) {
+        const RayRec q = rays[i];
+        const HitRec hr = hits[i];
+        D3 contrib = mk(0.0, 0.0, 0.0);
+        if (shade_ray<F>(S, P, q, hr, E, contrib)) {
+            c = contrib;
+            pixel = q.pixel;
+        }
+    }
+    if (E.direct) {
+        if (pixel >= 0) deposit(E, P, accum, pixel, c);
+        return;
+    }
+    // runs of equal pixel: [first lane whose left neighbour differs, lane before the next such lane]
+    const int left = __shfl_up(pixel, 1);
+    const unsigned long long heads = __ballot(lane == 0 || left != pixel);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int run_end = above ? lane + __ffsll((long long)above) - 1 : 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double ox = __shfl_down(c.x, d), oy = __shfl_down(c.y, d), oz = __shfl_down(c.z, d);
+        if (lane + d <= run_end) { c.x += ox; c.y += oy; c.z += oz; }
+    }
+    if (pixel >= 0 && ((heads >> lane) & 1ull)) accum_add(accum, pixel, c);
 }
 
 // ------------------------------------------------------------------------------------------ k_resolve
@@ -669,10 +704,37 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     const size_t npix = (size_t)params.part_rows * params.width;
     if (npix == 0) return hipSuccess;
     hipError_t e;
-    if (ws.capacity == 0) {
+    // Queue capacity: what one chunk of primary rays and its children need, up to RT_QUEUE_RAYS (default 2^26 rays =
+    // 9.7 GB per queue; a frame that needs more is rendered in chunks of rows x samples and batches of rays).  Large
+    // queues mean few batches, i.e. few launches and few host round trips per level: HBM is there to be used.
+    const bool may_emit = !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
+    {
         const char* env = getenv("RT_QUEUE_RAYS");
-        size_t cap = env ? strtoull(env, nullptr, 10) : 0;
-        ws.capacity = cap >= 4096 ? cap : (size_t(1) << 24);
+        const size_t env_cap = env ? strtoull(env, nullptr, 10) : 0;
+        const size_t max_cap = env_cap >= 4096 ? env_cap : (size_t(1) << 26);
+        size_t fan = 1;
+        if (may_emit) {
+            const size_t refl = (params.max_depth < params.max_bounces) ? 1 : (size_t)std::max(params.glossy_samples, 1);
+            fan = refl + 1 + (params.shadows ? 2ull * (size_t)scene.n_lights * (size_t)params.shadow_samples : 0ull);
+        }
+#ifndef RT_QUEUE_MIN_LOG2
+#define RT_QUEUE_MIN_LOG2 16
+#endif
+        size_t want = size_t(1) << RT_QUEUE_MIN_LOG2;
+        while (want < max_cap && want < npix * (size_t)params.spp * fan) want <<= 1;
+        want = std::min(want, max_cap);
+        if (ws.capacity != 0 && ws.capacity < want) {   // a larger frame than before: drop the queues (nothing is in flight on this stream's workspace after the sync)
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            for (void* p : ws.queues) (void)hipFree(p);
+            for (void* p : ws.hit_buffers) (void)hipFree(p);
+            ws.queues.clear();
+            ws.hit_buffers.clear();
+            ws.in_use.clear();
+            ws.capacity = want;
+        }
+        if (ws.capacity == 0) ws.capacity = want;
+    }
+    if (!ws.counters) {
         if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), (kNextBase + kXcds * kNextStride) * sizeof(unsigned))) != hipSuccess) return e;
         if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return e;
         int dev = 0, cus = 256;
@@ -692,7 +754,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
     const size_t first_event = ws.events_used;
     Driver D{scene, params, ws, stream, 0, 0};
-    D.may_emit = !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
+    D.may_emit = may_emit;
     if (!D.may_emit && params.spp == 1) D.direct = d_rgb8;
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
@@ -702,7 +764,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
 
     // Primary rays are generated in chunks of whole 8-row bands x a batch of samples, sized so that the first
     // level's children always fit one queue.
-    const size_t fo0 = D.fanout(0);
+    const size_t fo0 = may_emit ? D.fanout(0) : 1;   // nothing is queued behind the primary rays of such a frame
     const size_t max_primary = std::max<size_t>(64, ws.capacity / fo0);
     const int W = params.width;
     int ns = (int)std::min<size_t>((size_t)params.spp, std::max<size_t>(1, max_primary / ((size_t)W * 8)));

@@ -1,0 +1,49 @@
+"""Secondary measurements (not the driver's bench line): the other BASELINE configs at full resolution on one GPU.
+Scenes are the committed golden fixtures with only their `resolution` line changed.  Prints one JSON line each."""
+import json, os, re, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import helpers
+import raytracer_amd as rt
+
+CASES = [  # label, golden case, width, height, spp, rng
+    ("C1 default scene, Whitted 1 spp", "c1_default", 1920, 1080, 1, "d0"),
+    ("C1 + --shadows --fresnel", "c1_shadows_fresnel", 1920, 1080, 1, "d0"),
+    ("C3 dof: soft shadows + glossy + DoF, 64 spp", "st_dof", 1920, 1080, 64, "seeded"),
+    ("C4-like: displaced/textured shapes + env + glass, ACES/filmic", "own_complex", 1920, 1080, 1, "d0"),
+    ("C4-like: glass + HDR environment", "own_glass_env", 1920, 1080, 1, "d0"),
+    ("C5-like: motion blur + area lights, 4K 16 spp", "st_motion_blur", 3840, 2160, 16, "seeded"),
+]
+
+def load(name, w, h, spp, rng):
+    with open(os.path.join(helpers.GOLD, "configs", name + ".json")) as f:
+        cfg = rt.Config(text=f.read())
+    kw, shutter = helpers.flags_to_kwargs(helpers.MANIFEST[name]["flags"])
+    kw["aa"] = spp
+    if rng == "seeded": kw["seed"] = 7
+    with open(os.path.join(helpers.GOLD, "scenes", name + ".txt"), newline="") as f:
+        text = f.read()
+    text, n = re.subn(r"(?im)^(\s*resolution\s+)\d+\s+\d+", lambda m: "%s%d %d" % (m.group(1), w, h), text)
+    assert n == 1, name
+    scene = rt.SceneFile(text=text, texture_root=os.path.join(helpers.GOLD, "scenes"), config=cfg, shutter_time=shutter)
+    return scene, cfg.params(rng=rng, **kw)
+
+def main():
+    rt.init(0)
+    only = sys.argv[1:]
+    for label, name, w, h, spp, rng in CASES:
+        if only and name not in only: continue
+        sf, params = load(name, w, h, spp, rng)
+        scene = rt.Scene(sf)
+        scene.render(params)   # warm-up (allocates queues)
+        t0 = time.perf_counter()
+        img, st = scene.render(params, stats=True)
+        wall = (time.perf_counter() - t0) * 1e3
+        print(json.dumps({"config": label, "case": name, "resolution": [w, h], "spp": spp, "rays": int(st.rays),
+                          "kernel_ms": round(st.kernel_ms, 3), "traverse_ms": round(st.traverse_ms, 3), "wall_ms": round(wall, 3),
+                          "Mrays_per_s": round(st.rays / st.kernel_ms / 1e3, 1), "mean_pixel": round(float(img.mean()), 2)}), flush=True)
+        scene.close()
+
+if __name__ == "__main__":
+    main()
