@@ -219,6 +219,18 @@ int rt_scene_bvh_info(rt_scene_t scene, RtBvhInfo* out);
 /* Same build without any device work: returns the facts and, when order_out != NULL (n_shapes ints), the
  * depth-first leaf order of the shapes — the order the reference's BVHNode::intersect visits them. */
 int rt_bvh_build_host(const RtSceneDesc* desc, RtBvhInfo* info_out, int32_t* order_out);
+/* The hierarchy as the device traverses it (also host-only): a binned-SAH tree over the reference's per-shape boxes
+ * (transformed_shape.h:42-77, plane.cpp:11-46), collapsed to four children per 64-byte node with child boxes quantised
+ * outward to 8 bits per plane.  Node layout (little endian, 16 dwords): float org[3]; u32 exps (biased FP32 exponent
+ * of the grid step per axis, x | y<<8 | z<<16); u32 qlo[3], qhi[3] (per axis, byte c = plane of child c: plane =
+ * org + q * 2^(exp-127)); i32 child[4] (>= 0 node index, < 0 leaf: ~child = first_primitive << 1 | (count - 1),
+ * 0x7fffffff unused); 2 dwords padding.  Primitives are numbered in the reference's depth-first order
+ * (rt_bvh_build_host's order_out).  nodes_out: room for max_nodes nodes or NULL; info_out: counts, depth in 4-wide
+ * levels and the widened FP32 root box; root_ref_out: node 0 or a leaf reference; pad_out: the outward pad applied to
+ * every box before quantisation; prim_boxes_out: n_shapes x {min xyz, max xyz} in primitive order, or NULL.
+ * For tests of the host builder; the reference has its pointer tree only (bvh.h:37-39). */
+int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_nodes, RtBvhInfo* info_out, int32_t* root_ref_out,
+                        double* pad_out, double* prim_boxes_out);
 
 /* ---- render ------------------------------------------------------------------------------------ */
 

@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "rt_config_parse", "rt_config_get_int", "rt_config_get_double", "rt_config_get_bool", "rt_config_destroy",
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
-    "rt_version", "rt_traverse_time",
+    "rt_version", "rt_traverse_time", "rt_bvh_device_image",
 ]
 
 
@@ -150,6 +150,8 @@ def _load():
         "rt_scene_bvh_info": (i32, [vp, C.POINTER(RtBvhInfo)]),
         "rt_bvh_build_host": (i32, [C.POINTER(RtSceneDesc), C.POINTER(RtBvhInfo), C.POINTER(C.c_int32)]),
         "rt_traverse_time": (i32, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "rt_bvh_device_image": (i32, [C.POINTER(RtSceneDesc), vp, C.c_int32, C.POINTER(RtBvhInfo), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_double), vp]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
         "rt_part_rows": (i32, [i32, i32, i32, i32]),
@@ -361,6 +363,23 @@ def bvh_build_host(scene_desc):
     order = np.zeros(max(1, d.contents.n_shapes), dtype=np.int32)
     _check(lib.rt_bvh_build_host(d, C.byref(info), order.ctypes.data_as(C.POINTER(C.c_int32))))
     return info, order[: d.contents.n_shapes]
+
+
+NODE4_DTYPE = np.dtype([("org", "<f4", 3), ("exps", "<u4"), ("qlo", "<u4", 3), ("qhi", "<u4", 3), ("child", "<i4", 4),
+                        ("pad", "<i4", 2)])   # device_types.h: DNode4 (64 bytes)
+EMPTY_CHILD = 0x7FFFFFFF
+
+
+def bvh_device_image(scene_desc):
+    """The hierarchy as the device traverses it, built on the host (no GPU): dict with `nodes` (structured array of
+    NODE4_DTYPE), `info` (RtBvhInfo of the 4-wide tree), `root_ref`, `pad` and `prim_boxes` [n, 6] in primitive order."""
+    d = scene_desc.desc_ptr()
+    n = d.contents.n_shapes
+    nodes = np.zeros(max(1, n), dtype=NODE4_DTYPE)
+    boxes = np.zeros((max(1, n), 6), dtype=np.float64)
+    info, root, pad = RtBvhInfo(), C.c_int32(0), C.c_double(0.0)
+    _check(lib.rt_bvh_device_image(d, nodes.ctypes.data, len(nodes), C.byref(info), C.byref(root), C.byref(pad), boxes.ctypes.data))
+    return {"nodes": nodes[: info.n_nodes], "info": info, "root_ref": root.value, "pad": pad.value, "prim_boxes": boxes[:n]}
 
 
 def part_rows(height, tile_rows, part_index, part_count):

@@ -198,6 +198,20 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
     return h;
 }
 
+// The hierarchy the device traverses, from the reference-topology tree that fixes the primitive order.
+static HostBvh traversal_tree(const RtSceneDesc& desc, const HostBvh& ref) {
+    const char* e = std::getenv("RT_BVH_BUILDER");   // "median": traverse the reference topology itself (A/B runs)
+    if (e && std::string(e) == "median") return ref;
+    std::vector<Box> boxes(desc.n_shapes);
+    for (int k = 0; k < desc.n_shapes; ++k) boxes[k] = shape_bounds(desc.shapes[ref.order[k]], desc.shutter_time);
+    return build_traversal_bvh(boxes, kMaxBinaryDepth);
+}
+static Bvh4 device_image(const RtSceneDesc& desc, const HostBvh& trav) {
+    double max_origin = 0.0;
+    for (int a = 0; a < 3; ++a) max_origin = std::max(max_origin, std::fabs(desc.camera.location[a]));
+    return to_node4(trav, max_origin);
+}
+
 extern "C" {
 
 const char* rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
@@ -251,6 +265,35 @@ int rt_bvh_build_host(const RtSceneDesc* desc, RtBvhInfo* info, int32_t* order_o
     return RT_OK;
 }
 
+int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_nodes, RtBvhInfo* info_out, int32_t* root_ref_out,
+                        double* pad_out, double* prim_boxes_out) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    HostBvh ref = build_bvh(*desc);
+    HostBvh trav = traversal_tree(*desc, ref);
+    Bvh4 b4 = device_image(*desc, trav);
+    if (info_out) {
+        info_out->n_nodes = static_cast<int32_t>(b4.nodes.size());
+        info_out->n_prims = desc->n_shapes;
+        info_out->max_depth = b4.max_depth;
+        info_out->node_bytes = kNodeBytes;
+        for (int a = 0; a < 3; ++a) { info_out->root_min[a] = b4.root_lo[a]; info_out->root_max[a] = b4.root_hi[a]; }
+    }
+    if (root_ref_out) *root_ref_out = b4.root_ref;
+    if (pad_out) *pad_out = b4.pad;
+    if (nodes_out) {
+        if (static_cast<size_t>(std::max(max_nodes, 0)) < b4.nodes.size()) return fail(RT_ERR_LIMIT, "nodes_out is too small");
+        if (!b4.nodes.empty()) std::memcpy(nodes_out, b4.nodes.data(), b4.nodes.size() * sizeof(DNode4));
+    }
+    if (prim_boxes_out)
+        for (int k = 0; k < desc->n_shapes; ++k) {
+            Box b = shape_bounds(desc->shapes[ref.order[k]], desc->shutter_time);
+            store(prim_boxes_out + 6 * k, b.lo);
+            store(prim_boxes_out + 6 * k + 3, b.hi);
+        }
+    return RT_OK;
+}
+
 int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -264,16 +307,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     sc->width = desc->camera.resolution_x;
     sc->height = desc->camera.resolution_y;
     sc->bvh = build_bvh(*desc);
-    {
-        const char* e = std::getenv("RT_BVH_BUILDER");   // "median": traverse the reference topology itself (A/B runs)
-        if (e && std::string(e) == "median") {
-            sc->trav = sc->bvh;
-        } else {
-            std::vector<Box> boxes(desc->n_shapes);
-            for (int k = 0; k < desc->n_shapes; ++k) boxes[k] = shape_bounds(desc->shapes[sc->bvh.order[k]], desc->shutter_time);
-            sc->trav = build_traversal_bvh(boxes, kMaxBinaryDepth);
-        }
-    }
+    sc->trav = traversal_tree(*desc, sc->bvh);
     // A 4-wide node defers at most three children per level, and the collapsed tree is never deeper than the binary one.
     if (3 * sc->trav.max_depth > kTravStackDepth)
         return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + " entries)");
@@ -286,9 +320,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         return code;
     };
     DNode4* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
-    double max_origin = 0.0;
-    for (int a = 0; a < 3; ++a) max_origin = std::max(max_origin, std::fabs(desc->camera.location[a]));
-    Bvh4 b32 = to_node4(sc->trav, max_origin);
+    Bvh4 b32 = device_image(*desc, sc->trav);
     sc->n_nodes4 = static_cast<int32_t>(b32.nodes.size());
     sc->depth4 = b32.max_depth;
     if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);

@@ -4,9 +4,9 @@ tag=$1
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench.json 2> $out/bench.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > $out/bench.json 2> $out/bench.err || exit 1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
-pass() { name=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_$name.err || return 1; }
+pass() { name=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 > /dev/null 2> $out/pmc_$name.err || return 1; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY || exit 1
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 || exit 1
 pass tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum || exit 1
