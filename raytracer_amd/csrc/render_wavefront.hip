@@ -51,6 +51,53 @@ struct alignas(16) HitRec {
 };
 static_assert(sizeof(HitRec) == 32, "HitRec size");
 
+// Queues in HBM are stored as planes of 16-byte pieces (piece k of record i at p[k * stride + i], stride = queue
+// capacity): consecutive lanes work on consecutive records, so every load / store instruction of a wave covers 1 KB of
+// contiguous memory instead of 64 pieces 112 bytes apart.
+typedef unsigned rt_q4 __attribute__((ext_vector_type(4)));
+struct RayQ {
+    rt_q4* p;
+    unsigned stride;
+};
+struct HitQ {
+    rt_q4* p;
+    unsigned stride;
+};
+union RayBits {
+    RayRec r;
+    rt_q4 v[7];
+    __device__ RayBits() {}
+};
+union HitBits {
+    HitRec h;
+    rt_q4 v[2];
+    __device__ HitBits() {}
+};
+__device__ __forceinline__ RayRec ray_load(const RayQ q, unsigned i) {
+    RayBits b;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    return b.r;
+}
+__device__ __forceinline__ void ray_store(const RayQ q, unsigned i, const RayRec& r) {
+    RayBits b;
+    b.r = r;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
+}
+__device__ __forceinline__ HitRec hit_load(const HitQ q, unsigned i) {
+    HitBits b;
+    b.v[0] = q.p[i];
+    b.v[1] = q.p[(size_t)q.stride + i];
+    return b.h;
+}
+__device__ __forceinline__ void hit_store(const HitQ q, unsigned i, const HitRec& h) {
+    HitBits b;
+    b.h = h;
+    q.p[i] = b.v[0];
+    q.p[(size_t)q.stride + i] = b.v[1];
+}
+
 struct Chunk {
     int row0, rows;     // compact rows [row0, row0 + rows) of this part
     int s0, ns;         // samples [s0, s0 + ns) of every pixel
@@ -73,7 +120,7 @@ __device__ __forceinline__ unsigned emit_slot(unsigned* count) {
     return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-__device__ __forceinline__ void emit_ray(RayRec* out, unsigned* count, unsigned cap, unsigned* overflow, D3 o, D3 d, D3 w, double time,
+__device__ __forceinline__ void emit_ray(const RayQ out, unsigned* count, unsigned cap, unsigned* overflow, D3 o, D3 d, D3 w, double time,
                                          double tmax, unsigned long long rng, int pixel, int depth, int kind) {
     unsigned slot = emit_slot(count);
     if (slot >= cap) { *overflow = 1u; return; }   // the host sizes batches so that this cannot happen; it checks the flag
@@ -82,7 +129,50 @@ __device__ __forceinline__ void emit_ray(RayRec* out, unsigned* count, unsigned 
     r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
     r.w[0] = w.x; r.w[1] = w.y; r.w[2] = w.z;
     r.time = time; r.tmax = tmax; r.rng = rng; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
-    out[slot] = r;
+    ray_store(out, slot, r);
+}
+
+// Several rays per lane with ONE atomic per wave (the queue's tail is a single word: returning atomics on it serialise
+// in L2, and one atomic per emitted ray and wave made that word the bottleneck of shading-heavy frames).
+// emit_reserve: every calling lane gets `per_lane` slots (the same number in all lanes); ray j of this lane goes to
+// first + j * lanes, so that the lanes of a wave still write neighbouring slots.
+__device__ __forceinline__ unsigned emit_reserve(unsigned* count, unsigned per_lane, unsigned& lanes) {
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    lanes = (unsigned)__popcll(m);
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, lanes * per_lane);
+    base = __shfl(base, leader);
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+// emit_reserve_counted: lane-dependent counts; this lane's rays go to [first, first + mine).
+__device__ __forceinline__ unsigned emit_reserve_counted(unsigned* count, unsigned mine) {
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    // counts are small and this runs once per reflecting hit: walk the calling lanes in order (uniform loop over m)
+    unsigned before = 0, total = 0;
+    for (unsigned long long rest = m; rest != 0ull; rest &= rest - 1ull) {
+        const int src = __ffsll((long long)rest) - 1;
+        const unsigned c = __shfl(mine, src);
+        if (src < lane) before += c;
+        total += c;
+    }
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, total);
+    base = __shfl(base, leader);
+    return base + before;
+}
+__device__ __forceinline__ void emit_ray_at(const RayQ out, unsigned slot, unsigned cap, unsigned* overflow, D3 o, D3 d, D3 w, double time,
+                                            double tmax, unsigned long long rng, int pixel, int depth, int kind) {
+    if (slot >= cap) { *overflow = 1u; return; }
+    RayRec r;
+    r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
+    r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
+    r.w[0] = w.x; r.w[1] = w.y; r.w[2] = w.z;
+    r.time = time; r.tmax = tmax; r.rng = rng; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
+    ray_store(out, slot, r);
 }
 
 // ------------------------------------------------------------------------------------------ k_raygen
@@ -102,7 +192,7 @@ __device__ __forceinline__ void pixel_of(long long pix, int W, int rows, int& x,
     x = tx * 8 + rem % tw;
 }
 
-__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const Chunk ck, RayRec* __restrict__ out, long long n,
+__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const Chunk ck, const RayQ out, long long n,
                                                    unsigned* __restrict__ fetch_counters) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     // the traversal launched next on this stream starts with its queue fetch counters at zero (saves a memset launch)
@@ -128,7 +218,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
     r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z;
     r.w[0] = r.w[1] = r.w[2] = 1.0;
     r.time = time; r.tmax = 100000.0; r.rng = rng.next(); r.pixel = lr * P.width + x; r.depth = (short)P.max_depth; r.kind = kKindRadiance;
-    out[i] = r;
+    ray_store(out, (unsigned)i, r);
 }
 
 // ------------------------------------------------------------------------------------------ k_traverse
@@ -168,7 +258,7 @@ __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
 // timed variant carries neither the registers nor the instructions for them.
 template <int F, bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_TRAVERSE_WAVES)
-k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, HitRec* __restrict__ hits, const unsigned n,
+k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, const unsigned n,
            unsigned* __restrict__ next, unsigned long long* __restrict__ counters) {
     __shared__ unsigned long long stack_mem[kTravLdsEntries + 1][kBlock];   // + 1: the row branch-free pushes discard into
     TravStack stack;
@@ -219,7 +309,7 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
             const unsigned take = min((unsigned)__popcll(idle), avail);
             if (my == kNone && rank < take) {
                 my = chunk_next + rank;
-                const RayRec q = rays[my];
+                const RayRec q = ray_load(rays, my);
                 r.o = ld3(q.o);
                 r.d = ld3(q.d);
                 r.time = q.time;
@@ -292,7 +382,7 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
         if (my != kNone && cur == kDone && pend == 0) {
             HitRec h;
             h.t = best.t; h.bu = best.bu; h.bv = best.bv; h.prim = best.prim; h.tri = best.tri;
-            hits[my] = h;
+            hit_store(hits, my, h);
             my = kNone;
             if (COUNT) { max_visits = max(max_visits, ray_visits); ray_visits = 0; }
         }
@@ -318,7 +408,7 @@ k_traverse(const DScene S, const DParams P, const RayRec* __restrict__ rays, Hit
 
 // ------------------------------------------------------------------------------------------ k_shade
 struct EmitCtx {
-    RayRec* out;
+    RayQ out;
     unsigned* count;
     unsigned* overflow;
     unsigned cap;
@@ -458,6 +548,9 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
             // term (shading.h:154,192), shadow_samples rays each; a ray that reaches the light adds weight/samples.
             const double inv_s = 1.0 / P.shadow_samples;
             const D3 org = Pt + N * P.eps_shadow;
+            unsigned lanes = 0;
+            const unsigned first = emit_reserve(E.count, 2u * (unsigned)P.shadow_samples, lanes);   // one atomic per wave and light
+            unsigned j = 0;
             for (int pass = 0; pass < 2; ++pass) {
                 const D3 wt = (pass == 0) ? cmul(w, diff * ad_weight) * inv_s : cmul(w, sp) * inv_s;
                 for (int k = 0; k < P.shadow_samples; ++k) {
@@ -466,7 +559,8 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
                     D3 d = lp - Pt;
                     double dist = length(d);
                     d = normalize(d);
-                    emit_ray(E.out, E.count, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth, kKindShadow);
+                    emit_ray_at(E.out, first + j * lanes, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth, kKindShadow);
+                    ++j;
                 }
             }
         }
@@ -487,11 +581,23 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         D3 org = h.p + h.n * eps;
         if (samples > 0) {
             wr = wr * (1.0 / samples);
+            // samples below the surface are dropped (tracer.h:196-204): count the kept ones first with a copy of the
+            // random stream, reserve their slots with one atomic per wave, then draw the same samples again and queue them
+            unsigned kept = 0;
+            {
+                Rng dry = rng;
+                for (int k = 0; k < samples; ++k) {
+                    D3 off = dry.in_unit_sphere() * rough;
+                    D3 target = normalize(perfect + off);
+                    if (dot(target, h.n) > 0) { ++kept; (void)dry.next(); }
+                }
+            }
+            unsigned slot = emit_reserve_counted(E.count, kept);
             for (int k = 0; k < samples; ++k) {
                 D3 off = rng.in_unit_sphere() * rough;
                 D3 target = normalize(perfect + off);
                 if (dot(target, h.n) > 0)
-                    emit_ray(E.out, E.count, E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+                    emit_ray_at(E.out, slot++, E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
             }
         } else {
             emit_ray(E.out, E.count, E.cap, E.overflow, org, perfect, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
@@ -511,16 +617,16 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 // other with the same pixel -- the samples of one pixel and their children stay neighbours in the queues -- are summed
 // inside the wave first and only the first lane of each run issues the three atomics.
 template <int F>
-__global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayRec* __restrict__ rays,
-                                                  const HitRec* __restrict__ hits, const unsigned n, const EmitCtx E,
+__global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayQ rays,
+                                                  const HitQ hits, const unsigned n, const EmitCtx E,
                                                   double* __restrict__ accum) {
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     D3 c = mk(0.0, 0.0, 0.0);
     int pixel = -1 - lane;   // lanes without a contribution: a run of their own
     if (i < n) {
-        const RayRec q = rays[i];
-        const HitRec hr = hits[i];
+        const RayRec q = ray_load(rays, i);
+        const HitRec hr = hit_load(hits, i);
         D3 contrib = mk(0.0, 0.0, 0.0);
         if (shade_ray<F>(S, P, q, hr, E, contrib)) {
             c = contrib;
@@ -589,8 +695,8 @@ struct Driver {
         if (e != hipSuccess && err == hipSuccess) err = e;
         return err == hipSuccess;
     }
-    RayRec* rays(int q) { return static_cast<RayRec*>(ws.queues[q]); }
-    HitRec* hits(int q) { return static_cast<HitRec*>(ws.hit_buffers[q]); }
+    RayQ rays(int q, unsigned start = 0) { return RayQ{static_cast<rt_q4*>(ws.queues[q]) + start, (unsigned)ws.capacity}; }
+    HitQ hits(int q, unsigned start = 0) { return HitQ{static_cast<rt_q4*>(ws.hit_buffers[q]) + start, (unsigned)ws.capacity}; }
 
     int acquire() {
         for (size_t i = 0; i < ws.queues.size(); ++i)
@@ -643,8 +749,8 @@ struct Driver {
                                ws.counters + kNextBase, ws.stats);
     }
     template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo) {
-        EmitCtx E{qo >= 0 ? rays(qo) : nullptr, ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
-        hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q) + start, hits(q) + start, n,
+        EmitCtx E{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
+        hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
                            E, ws.accum);
     }
 
