@@ -247,6 +247,15 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);
 
+/* Linear radiance: the per-pixel average over the samples BEFORE tone mapping and 8-bit truncation (the `avg_colour`
+ * of main.cpp:306-308), 3 doubles per pixel, row-major, top row first.  For float (PFM) output and for progressive /
+ * resumable accumulation: frames rendered with different seeds average to a frame of the summed sample count; apply
+ * tracer.h:23-54,297-308 afterwards (raytracer_amd.progressive does).  Wavefront schedule only.  rt_render_linear writes
+ * a whole frame to host memory; rt_render_linear_device writes this part's rows (compact, tile order) to device memory
+ * asynchronously on `hip_stream`.  The reference only ever stores the tone-mapped bytes. */
+int rt_render_linear(rt_scene_t scene, const RtRenderParams* params, double* rgb_out);
+int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb_f64, void* hip_stream);
+
 /* Device time (hipEvents on the launch stream) of the BVH-traversal kernel launches that rt_render_device enqueued on
  * `hip_stream` for this scene since the last call of this function, and how many launches that was.  The stream must
  * have been synchronised by the caller (RT_ERR_DEVICE otherwise).  No counterpart in the reference: it feeds the
@@ -291,6 +300,9 @@ int rt_shapes_from_trs(int n, const double* trs, RtShape* shapes);
 
 /* `Image::write` (Image.cpp:170-188): "P6\nW H\n255\n" + bytes.  `Image::read` (Image.cpp:84-167): P3/P6. */
 int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgb);
+/* "PF" portable float map, little endian, rows bottom to top (readable by rt_read_pfm / HDRImage::load); rgb is the
+ * top-first double frame of rt_render_linear. */
+int rt_write_pfm(const char* path, int width, int height, const double* rgb);
 int rt_read_ppm(const char* path, int* width, int* height, uint8_t** rgb_out /* free with rt_free */);
 /* `HDRImage::load` (HDRImage.cpp:22-109): "PF" portable float map. */
 int rt_read_pfm(const char* path, int* width, int* height, float** rgb_out /* free with rt_free */);

@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "rt_config_parse", "rt_config_get_int", "rt_config_get_double", "rt_config_get_bool", "rt_config_destroy",
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
-    "rt_version", "rt_traverse_time", "rt_bvh_device_image",
+    "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
 ]
 
 
@@ -150,6 +150,9 @@ def _load():
         "rt_scene_bvh_info": (i32, [vp, C.POINTER(RtBvhInfo)]),
         "rt_bvh_build_host": (i32, [C.POINTER(RtSceneDesc), C.POINTER(RtBvhInfo), C.POINTER(C.c_int32)]),
         "rt_traverse_time": (i32, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "rt_render_linear": (i32, [vp, C.POINTER(RtRenderParams), vp]),
+        "rt_render_linear_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp]),
+        "rt_write_pfm": (i32, [cp, i32, i32, vp]),
         "rt_bvh_device_image": (i32, [C.POINTER(RtSceneDesc), vp, C.c_int32, C.POINTER(RtBvhInfo), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_double), vp]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
@@ -413,6 +416,15 @@ class Scene:
         _check(lib.rt_render(self._h, C.byref(params), img.ctypes.data, C.byref(st) if stats else None))
         return (img, st) if stats else img
 
+    def render_linear(self, params):
+        """One frame of linear radiance (before tone mapping): float64 [H, W, 3] (see rt_render_linear)."""
+        img = np.zeros((self.height, self.width, 3), dtype=np.float64)
+        _check(lib.rt_render_linear(self._h, C.byref(params), img.ctypes.data))
+        return img
+
+    def render_linear_device(self, params, d_rgb_f64_ptr, stream=None):
+        _check(lib.rt_render_linear_device(self._h, C.byref(params), d_rgb_f64_ptr, stream))
+
     def render_device(self, params, d_rgb8_ptr, d_counters_ptr=None, collect_counters=False, stream=None):
         """Asynchronous render of this part's rows into device memory (see rt_render_device)."""
         _check(lib.rt_render_device(self._h, C.byref(params), d_rgb8_ptr, d_counters_ptr, int(collect_counters), stream))
@@ -430,6 +442,11 @@ class Scene:
 
     def __del__(self):
         self.close()
+
+
+def write_pfm(path, img):
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    _check(lib.rt_write_pfm(os.fsencode(path), img.shape[1], img.shape[0], img.ctypes.data))
 
 
 def write_ppm(path, img):

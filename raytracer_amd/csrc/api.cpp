@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -470,6 +471,44 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     return RT_OK;
 }
 
+int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb_f64, void* hip_stream) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!d_rgb_f64) return fail(RT_ERR_INVALID, "d_rgb_f64 is NULL");
+    DParams dp;
+    int rc = make_dparams(scene, params, 0, &dp);
+    if (rc) return rc;
+    if (params->schedule != RT_SCHEDULE_WAVEFRONT) return fail(RT_ERR_INVALID, "linear output needs the wavefront schedule");
+    if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
+    if (dp.part_rows == 0) return RT_OK;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
+    WavefrontWorkspace* ws;
+    {
+        std::lock_guard<std::mutex> lock(scene->wf_mutex);
+        ws = &scene->wf[st];
+    }
+    hipError_t e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, *ws, static_cast<double*>(d_rgb_f64));
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_linear(rt_scene_t scene, const RtRenderParams* params, double* rgb_out) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!scene || !params || !rgb_out) return fail(RT_ERR_INVALID, "NULL argument");
+    if (params->part_count > 1) return fail(RT_ERR_INVALID, "rt_render_linear renders whole frames (use rt_render_linear_device for parts)");
+    HIP_TRY(hipSetDevice(g_dev.device));
+    const size_t bytes = static_cast<size_t>(scene->width) * scene->height * 3 * sizeof(double);
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    int rc = rt_render_linear_device(scene, params, d, g_dev.stream);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(rgb_out, d, bytes, hipMemcpyDeviceToHost, g_dev.stream);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(g_dev.stream);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("linear frame copy: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_traverse_time(rt_scene_t scene, void* hip_stream, double* ms_out, uint64_t* launches_out) {
     if (!scene || !ms_out || !launches_out) return fail(RT_ERR_INVALID, "NULL argument");
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
@@ -626,6 +665,22 @@ int rt_shapes_from_trs(int n, const double* trs, RtShape* shapes) {
         return fail(RT_ERR_INVALID, e.what());
     }
     return RT_OK;
+}
+
+int rt_write_pfm(const char* path, int width, int height, const double* rgb) {
+    if (!path || !rgb || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RT_ERR_IO, std::string("Could not open PFM file for writing: ") + path);
+    std::fprintf(f, "PF\n%d %d\n-1.0\n", width, height);   // negative scale: little endian
+    std::vector<float> row(static_cast<size_t>(width) * 3);
+    bool ok = true;
+    for (int y = height - 1; y >= 0 && ok; --y) {   // PFM rows run bottom to top (HDRImage.cpp:112-182 reads them that way)
+        const double* src = rgb + static_cast<size_t>(y) * width * 3;
+        for (size_t i = 0; i < row.size(); ++i) row[i] = static_cast<float>(src[i]);
+        ok = std::fwrite(row.data(), sizeof(float), row.size(), f) == row.size();
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : fail(RT_ERR_IO, std::string("short write: ") + path);
 }
 
 int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {

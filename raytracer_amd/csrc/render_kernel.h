@@ -35,8 +35,9 @@ void wavefront_workspace_free(WavefrontWorkspace& ws);
 
 // Wavefront schedule (render_wavefront.hip): same pixels; work is enqueued on `stream`, and the call returns after the
 // last queue has been drained (it reads queue sizes back between levels).
+// d_linear != NULL: instead of RGB8, write the per-pixel average before tone mapping as 3 doubles per pixel.
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws);
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear = nullptr);
 
 // Device time of the k_traverse launches enqueued through `ws` since the last collection (their stream must have been
 // synchronised: hipErrorNotReady otherwise), and how many launches that was.

@@ -672,6 +672,13 @@ __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, u
     }
 }
 
+// Linear radiance (the average before tone mapping) for float output and progressive accumulation.
+__global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const int n3,
+                                                           const int spp) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n3) out[i] = accum[i] * (1.0 / spp);
+}
+
 // ------------------------------------------------------------------------------------------ host driver
 constexpr int kSpheres = RT_FEAT_SPHERE;
 constexpr int kAnalytic = RT_FEAT_SPHERE | RT_FEAT_QUAD | RT_FEAT_CUBE;
@@ -806,7 +813,7 @@ void wavefront_workspace_free(WavefrontWorkspace& ws) {
 }
 
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws) {
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear) {
     const size_t npix = (size_t)params.part_rows * params.width;
     if (npix == 0) return hipSuccess;
     hipError_t e;
@@ -861,7 +868,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     const size_t first_event = ws.events_used;
     Driver D{scene, params, ws, stream, 0, 0};
     D.may_emit = may_emit;
-    if (!D.may_emit && params.spp == 1) D.direct = d_rgb8;
+    if (!D.may_emit && params.spp == 1 && !d_linear) D.direct = d_rgb8;
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
@@ -889,7 +896,10 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         }
     }
     if (D.err != hipSuccess) return D.err;
-    if (!D.direct)
+    if (d_linear)
+        hipLaunchKernelGGL(k_resolve_linear, dim3((unsigned)((npix * 3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_linear,
+                           (int)(npix * 3), params.spp);
+    else if (!D.direct)
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
                            params.spp, params.tonemap);
     // Rays are counted on the host (every traversed queue entry is one closest-hit query).  With count_tests the call
