@@ -5,7 +5,7 @@
 // Reference flags (main.cpp:82-216): --no-bvh --time N --aa N --exposure F --shadows --glossy --parallel
 //   --motion-blur F --fresnel --normals --bvh_testing --tonemap {reinhard|aces|filmic}; unknown arguments are ignored.
 // Added (no counterpart in the reference, whose paths are hard-coded relative to Code/<build>/):
-//   --scene PATH --config PATH --out PATH --texture-root DIR --device N --seed N --d0 --megakernel
+//   --scene PATH --config PATH --out PATH --texture-root DIR --device N --seed N --d0 --megakernel --pfm PATH
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -38,6 +38,7 @@ struct Options {
     int aa = 1;
     double exposure = 1.0, shutter = 0.0;
     unsigned long long seed = 1;
+    std::string pfm_path;
     std::string scene = "../../ASCII/scene.txt", config = "../config.json", out = "../../Output/scene_test.ppm", texture_root = "..";
     std::string all_args;
 };
@@ -90,6 +91,7 @@ int main(int argc, char* argv[]) {
             else if (a == "--seed" && i + 1 < argc) o.seed = std::stoull(argv[++i]);
             else if (a == "--d0") o.d0 = true;
             else if (a == "--megakernel") o.megakernel = true;
+            else if (a == "--pfm" && i + 1 < argc) o.pfm_path = argv[++i];   // also write the linear (pre tone map) frame
         } catch (const std::exception&) {
             std::cerr << "Error: Invalid value for " << a << " flag." << std::endl;
             return 1;
@@ -155,6 +157,17 @@ int main(int argc, char* argv[]) {
                     ok = false;
                 } else {
                     std::cout << "Image saved to '" << output_path << "'." << std::endl;
+                }
+            }
+            if (ok && !o.pfm_path.empty()) {   // linear radiance of the same frame (same seed: same samples), before tone mapping
+                std::vector<double> lin(static_cast<size_t>(w) * h * 3);
+                RtRenderParams ql = q;
+                ql.schedule = RT_SCHEDULE_WAVEFRONT;
+                if (rt_render_linear(sc, &ql, lin.data()) != RT_OK || rt_write_pfm(o.pfm_path.c_str(), w, h, lin.data()) != RT_OK) {
+                    std::cerr << "An error occurred: " << rt_last_error() << std::endl;
+                    ok = false;
+                } else {
+                    std::cout << "Linear frame saved to '" << o.pfm_path << "'." << std::endl;
                 }
             }
         }

@@ -17,7 +17,7 @@ def test_rtcli_renders_golden(tmp_path):
     out = str(tmp_path / "o.ppm")
     cmd = [os.path.join(ROOT, "raytracer_amd", "rtcli"), "--scene", os.path.join(helpers.GOLD, "scenes", name + ".txt"),
            "--config", os.path.join(helpers.GOLD, "configs", name + ".json"), "--texture-root", os.path.join(helpers.GOLD, "scenes"),
-           "--out", out, "--d0", "--bogus-flag", "7"] + helpers.MANIFEST[name]["flags"]
+           "--out", out, "--pfm", str(tmp_path / "o.pfm"), "--d0", "--bogus-flag", "7"] + helpers.MANIFEST[name]["flags"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert p.returncode == 0, p.stdout[-2000:]
     assert "Shadows enabled" in p.stdout and "Image saved to" in p.stdout
@@ -25,6 +25,11 @@ def test_rtcli_renders_golden(tmp_path):
     golden = np.load(os.path.join(helpers.GOLD, "images", name + ".npz"))["image"]
     mx, nd, n1 = helpers.diff_stats(img, golden)
     assert mx <= 1
+    # --pfm: the same frame before tone mapping (float32, bottom row first); tone-mapped on the host it is the PPM again
+    from raytracer_amd import progressive
+    lin = rt.read_pfm(str(tmp_path / "o.pfm"))[::-1]
+    mx, nd, n1 = helpers.diff_stats(progressive.to_image(lin, rt.RT_TONEMAP_NONE), img)
+    assert mx <= 1 and nd <= 0.01 * img.size
 
 
 def test_rtcli_missing_scene_fails(tmp_path):
