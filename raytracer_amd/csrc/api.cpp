@@ -116,6 +116,7 @@ struct HostArrays {
     std::vector<DLight> lights;
     int32_t features = 0;
     int32_t spawning_materials = 0;
+    int32_t transparent_materials = 0;
     DCamera cam{};
 };
 
@@ -171,6 +172,7 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
         o.pad = 0;
         if (o.texture >= 0 || o.bump >= 0) h.features |= RT_FEAT_TEXTURE;
         if (!(m.reflectivity <= 0.0) || !(m.transparency <= 0.0)) h.spawning_materials = 1;   // also NaN
+        if (!(m.transparency <= 0.0)) h.transparent_materials = 1;
     }
     h.lights.resize(d.n_lights);
     for (int i = 0; i < d.n_lights; ++i) {
@@ -361,7 +363,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     d.root_ref = b32.root_ref;
     d.features = h.features;
     d.spawning_materials = h.spawning_materials;
-    d.pad_root = 0;
+    d.transparent_materials = h.transparent_materials;
     for (int a = 0; a < 3; ++a) { d.root_lo[a] = b32.root_lo[a]; d.root_hi[a] = b32.root_hi[a]; }
     d.shutter_time = desc->shutter_time;
     d.cam = h.cam;

@@ -135,7 +135,7 @@ struct DScene {
     int32_t features;             // RT_FEAT_* bits: which code paths this scene can reach
     float root_lo[3], root_hi[3];   // widened like the node boxes
     int32_t spawning_materials;     // 1 when some material reflects or transmits (secondary radiance rays possible)
-    int32_t pad_root;
+    int32_t transparent_materials;  // 1 when some material transmits (shadow rays then need their CLOSEST occluder)
     double shutter_time;
     DCamera cam;
 };

@@ -280,6 +280,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
     Cand best{0.0, -1, 0, 0.0, 0.0};
     int best_order = 0, sp = 0, cur = kDone, pend = 0;   // pend: parked leaf reference (< 0) or 0; idle: cur == kDone, pend == 0
     bool best_incl = false;
+    bool any_hit = false;   // shadow ray in a scene without transmitting materials: any occluder ends it (shading.h:52-55)
     Counters C{0u, 0u, 0u, 0u};
     unsigned ray_visits = 0, max_visits = 0, iters = 0;   // statistics (COUNT only)
 
@@ -314,6 +315,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 r.d = ld3(q.d);
                 r.time = q.time;
                 const bool shadow = q.kind == kKindShadow;
+                any_hit = shadow && S.transparent_materials == 0;
                 tmin = shadow ? 0.001 : P.eps_scene;                       // shading.h:45 / tracer.h:152-156
                 const double tmax = shadow ? q.tmax - 0.001 : q.tmax;
                 best = Cand{tmax, -1, 0, 0.0, 0.0};
@@ -376,6 +378,9 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 if (code & 1) test_prim<F, COUNT>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
                 tmax32 = __double2float_ru(best.t);
                 pend = 0;
+                // The shading of an occluded shadow ray only asks whether its occluder transmits: with opaque materials
+                // only, the first occluder found answers for the closest one, and the ray is done.
+                if (any_hit && best.prim >= 0) { cur = kDone; sp = 0; }
             }
         }
         // ---- retire finished rays
