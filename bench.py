@@ -24,12 +24,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (4 by default) and kernels of streams that share a
-# queue run in order; the frames in flight below want one queue each.  Read by the HIP runtime when it starts.
+# queue run in order; the frames in flight below want one queue each (plus torch's and RCCL's own streams).  Read by the HIP runtime when it starts.
 try:
-    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
-        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
 except ValueError:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+# Throughput setting of the library: traversal grids of at least 8 rays per lane, so that the launches of the frames in
+# flight fit the GPU side by side when a rank's share of the frame is small (the default, 2, favours one frame's latency).
+os.environ.setdefault("RT_RAYS_PER_LANE", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

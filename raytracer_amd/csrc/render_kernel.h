@@ -30,6 +30,7 @@ struct WavefrontWorkspace {
     std::vector<hipEvent_t> events;      // start/stop pairs around the k_traverse launches not yet collected
     size_t events_used = 0;
     int compute_units = 256;
+    int rays_per_lane = 2;               // traversal grid sizing (RT_RAYS_PER_LANE)
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);
 

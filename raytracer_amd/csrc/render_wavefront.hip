@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 #define RT_NODE_VOTE 24           // run an interior-node step while at least this many lanes want one
 #endif
 #ifndef RT_RAYS_PER_LANE
-#define RT_RAYS_PER_LANE 2        // the traversal grid shrinks until every lane has this many rays to work through
+#define RT_RAYS_PER_LANE 2        // the traversal grid shrinks until every lane has this many rays to work through (default;
+                                  // environment RT_RAYS_PER_LANE overrides: larger = smaller grids = more launches side by side)
 #endif
 #ifndef RT_INNER_VOTE
 #define RT_INNER_VOTE 48          // stay in the node loop while at least this many lanes want another node
@@ -751,7 +752,8 @@ struct Driver {
     template <int F> void launch_traverse_kernel(int q, unsigned n) {
         // Persistent grid sized by the work: at least RT_RAYS_PER_LANE rays per lane, so that lanes can be refilled and
         // a small queue (a part of a frame, a deep level of the ray tree) leaves the other CUs to concurrent streams.
-        const unsigned want = (n + kBlock * RT_RAYS_PER_LANE - 1) / (kBlock * RT_RAYS_PER_LANE);
+        const unsigned per_block = kBlock * (unsigned)std::max(1, ws.rays_per_lane);
+        const unsigned want = (n + per_block - 1) / per_block;
         const unsigned blocks = std::max(1u, std::min((unsigned)traverse_blocks, want));
         if (P.count_tests)
             hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n,
@@ -859,6 +861,8 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         ws.compute_units = cus;
+        const char* rpl = getenv("RT_RAYS_PER_LANE");
+        ws.rays_per_lane = rpl ? std::max(1, atoi(rpl)) : RT_RAYS_PER_LANE;
     }
     if (ws.accum_pixels < npix) {
         if (ws.accum) (void)hipFree(ws.accum);
