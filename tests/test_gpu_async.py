@@ -81,3 +81,42 @@ def test_stress_frame_properties(gpu):
         frame[rows] = part[rows]
     assert np.array_equal(frame, img)
     scene.close()
+
+
+@pytest.mark.parametrize("name", ["c1_shadows_fresnel", "fin_glossy_on", "own_glass_env"])
+def test_small_queues_force_chunks_and_batches(gpu, name, monkeypatch):
+    """RT_QUEUE_RAYS at its minimum (4096 rays): the frame is generated in many chunks of 8-row bands and every level of
+    the ray tree is shaded in batches sized by its worst-case fan-out.  Same picture, same number of rays."""
+    scene_file, params, golden = helpers.load_case(name)
+    scene = rt.Scene(scene_file)
+    ref, st_ref = scene.render(params, stats=True)
+    scene.close()
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    scene = rt.Scene(scene_file)   # a new scene: the queue size is fixed when a scene's queues are first allocated
+    img, st = scene.render(params, stats=True)
+    scene.close()
+    mx, nd, n1 = helpers.diff_stats(img, ref)
+    assert mx <= 1 and nd <= 0.001 * img.size
+    assert st.rays == st_ref.rays
+    mx, nd, n1 = helpers.diff_stats(img, golden)
+    assert mx <= 1
+
+
+def test_empty_scene_is_background(gpu):
+    """No shapes at all: every pixel is the background colour of the config (tracer.h:282-293), on both schedules."""
+    cfg = workloads.default_config()
+    cam = rt.RtCamera()
+    cam.location[:] = [0, -3, 0]; cam.gaze_direction[:] = [0, 1, 0]; cam.up_vector[:] = [0, 0, 1]
+    cam.focal_length, cam.sensor_width, cam.sensor_height = 50, 36, 24
+    cam.resolution_x, cam.resolution_y, cam.f_stop, cam.focal_distance = 48, 27, 99999.0, 10.0
+    sb = rt.SceneBuilder(cam, [], rt.shapes_from_trs(np.zeros((0, 9))), [rt.default_material()])
+    params = cfg.params(rng="d0")
+    ref = oracle_py.render(sb, params)
+    scene = rt.Scene(sb)
+    for schedule in (rt.RT_SCHEDULE_WAVEFRONT, rt.RT_SCHEDULE_MEGAKERNEL):
+        p = params.copy()
+        p.schedule = schedule
+        img, st = scene.render(p, stats=True)
+        assert np.array_equal(img, ref) and st.rays == 48 * 27
+        assert len(np.unique(img.reshape(-1, 3), axis=0)) == 1
+    scene.close()
