@@ -10,9 +10,16 @@
 //
 // Why: on the 10^6-sphere frame a lane's traversal length varies by an order of magnitude inside one 8x8 tile, and a
 // one-lane-per-pixel megakernel idles 85 % of its lanes (measured).  k_traverse is a persistent kernel:
-// lanes that finish their ray immediately fetch the next one from the queue, and a wave votes on whether to spend the
-// next step on interior nodes or on the (much more expensive, FP64 sqrt/div) primitive tests.  Its register budget
-// is the ray, the best hit and two child boxes, which lets 2x as many waves stay resident as the megakernel's.
+// a wave reserves chunks of the queue (one share of it per XCD, so that an XCD's L2 sees neighbouring rays), lanes that
+// finish their ray take the next one at once, and the wave votes on whether to spend the next step on interior nodes
+// (a tight loop over 4-wide, 8-bit quantised nodes with a per-lane stack of (child, entry distance) in LDS) or on the
+// much more expensive FP64 primitive tests of the leaves its lanes have parked meanwhile.
+//
+// Two properties of this chip shape the rest (MI355X_MICROARCH.md): float atomics execute at the memory side at a few
+// G/s, and a returning atomic on one word serialises.  Hence contributions of neighbouring lanes to the same pixel
+// are summed inside the wave before the FP64 atomics, a hit reserves the queue slots of all its shadow rays (and of
+// all its kept glossy samples) with one atomic per wave, queues are planes of 16-byte pieces so that a wave's accesses
+// are contiguous, and a frame with one ray per pixel writes its pixels straight from the shading kernel.
 //
 // The colour of a ray is linear in the colours of its child rays (tracer.h:268-279) and in the visibility of each
 // light (shading.h:166-171, 206-211), so every queued ray carries the product of the weights above it and adds
