@@ -153,6 +153,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (launches + collectives), before waiting for the GPU
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -208,7 +209,7 @@ def main():
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
                        "frames_in_flight": F},
-            "ms_per_frame": round(ms_per_step, 4),
+            "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches_alone,
