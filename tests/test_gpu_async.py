@@ -120,3 +120,19 @@ def test_empty_scene_is_background(gpu):
         assert np.array_equal(img, ref) and st.rays == 48 * 27
         assert len(np.unique(img.reshape(-1, 3), axis=0)) == 1
     scene.close()
+
+
+def test_small_queues_with_many_samples(gpu, monkeypatch):
+    """16 spp through 4096-ray queues: primary rays are generated in chunks of rows x sample batches (the sample loop of
+    main.cpp:288 is split), and the seeded picture is the same as with one big queue (same samples, other summation order)."""
+    scene_file, params, hi, lo, psnr_ref = helpers.load_stochastic("st_soft_shadows", 16, 5)
+    scene = rt.Scene(scene_file)
+    ref = scene.render(params)
+    scene.close()
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    scene = rt.Scene(scene_file)
+    img, st = scene.render(params, stats=True)
+    scene.close()
+    mx, nd, n1 = helpers.diff_stats(img, ref)
+    assert mx <= 1 and nd <= 0.01 * img.size
+    assert helpers.psnr(img, hi) >= psnr_ref - 0.5 or helpers.psnr(img, hi) >= helpers.psnr(ref, hi) - 0.1
