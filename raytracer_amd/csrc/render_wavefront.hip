@@ -698,6 +698,8 @@ constexpr int kAnalytic = RT_FEAT_SPHERE | RT_FEAT_QUAD | RT_FEAT_CUBE;
 constexpr int kFull = kAnalytic | RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV;
 
 constexpr size_t kMaxTimedEvents = 8192;   // start/stop events kept per workspace until they are collected
+constexpr size_t kMinQueueRays = size_t(1) << 16;
+constexpr size_t kDefaultMaxQueueRays = size_t(1) << 26;   // 9.7 GB per queue (rays + hit records)
 
 struct Driver {
     const DScene& S;
@@ -838,16 +840,13 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     {
         const char* env = getenv("RT_QUEUE_RAYS");
         const size_t env_cap = env ? strtoull(env, nullptr, 10) : 0;
-        const size_t max_cap = env_cap >= 4096 ? env_cap : (size_t(1) << 26);
+        const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : kDefaultMaxQueueRays, size_t(1) << 31);   // slots are 32-bit
         size_t fan = 1;
         if (may_emit) {
             const size_t refl = (params.max_depth < params.max_bounces) ? 1 : (size_t)std::max(params.glossy_samples, 1);
             fan = refl + 1 + (params.shadows ? 2ull * (size_t)scene.n_lights * (size_t)params.shadow_samples : 0ull);
         }
-#ifndef RT_QUEUE_MIN_LOG2
-#define RT_QUEUE_MIN_LOG2 16
-#endif
-        size_t want = size_t(1) << RT_QUEUE_MIN_LOG2;
+        size_t want = kMinQueueRays;
         while (want < max_cap && want < npix * (size_t)params.spp * fan) want <<= 1;
         want = std::min(want, max_cap);
         if (ws.capacity != 0 && ws.capacity < want) {   // a larger frame than before: drop the queues (nothing is in flight on this stream's workspace after the sync)
@@ -888,7 +887,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
-    // persistent traversal grid: every CU gets RT_TRAVERSE_WAVES waves per SIMD (LDS: 24 KB per 256-thread block)
+    // persistent traversal grid: at most RT_TRAVERSE_WAVES waves per SIMD on every CU (LDS: 34 KB per 256-thread block)
     D.traverse_blocks = ws.compute_units * RT_TRAVERSE_WAVES;
 
     // Primary rays are generated in chunks of whole 8-row bands x a batch of samples, sized so that the first
