@@ -201,13 +201,23 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
     return h;
 }
 
+// RT_BUILD_TIMING=1: the phases of scene creation on stderr.
+struct BuildClock {
+    bool on = std::getenv("RT_BUILD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rt build] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 // The hierarchy the device traverses, from the reference-topology tree that fixes the primitive order.
 static HostBvh traversal_tree(const RtSceneDesc& desc, const HostBvh& ref) {
     const char* e = std::getenv("RT_BVH_BUILDER");   // "median": traverse the reference topology itself (A/B runs)
     if (e && std::string(e) == "median") return ref;
-    std::vector<Box> boxes(desc.n_shapes);
-    for (int k = 0; k < desc.n_shapes; ++k) boxes[k] = shape_bounds(desc.shapes[ref.order[k]], desc.shutter_time);
-    return build_traversal_bvh(boxes, kMaxBinaryDepth);
+    return build_traversal_bvh(shape_boxes(desc, ref.order.data()), kMaxBinaryDepth);
 }
 static Bvh4 device_image(const RtSceneDesc& desc, const HostBvh& trav) {
     double max_origin = 0.0;
@@ -272,9 +282,13 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
                         double* pad_out, double* prim_boxes_out) {
     int rc = validate_desc(desc);
     if (rc) return rc;
+    BuildClock clock;
     HostBvh ref = build_bvh(*desc);
+    clock.lap("reference-order tree");
     HostBvh trav = traversal_tree(*desc, ref);
+    clock.lap("traversal tree");
     Bvh4 b4 = device_image(*desc, trav);
+    clock.lap("4-wide image");
     if (info_out) {
         info_out->n_nodes = static_cast<int32_t>(b4.nodes.size());
         info_out->n_prims = desc->n_shapes;
@@ -288,12 +302,13 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
         if (static_cast<size_t>(std::max(max_nodes, 0)) < b4.nodes.size()) return fail(RT_ERR_LIMIT, "nodes_out is too small");
         if (!b4.nodes.empty()) std::memcpy(nodes_out, b4.nodes.data(), b4.nodes.size() * sizeof(DNode4));
     }
-    if (prim_boxes_out)
+    if (prim_boxes_out) {
+        const std::vector<Box> boxes = shape_boxes(*desc, ref.order.data());
         for (int k = 0; k < desc->n_shapes; ++k) {
-            Box b = shape_bounds(desc->shapes[ref.order[k]], desc->shutter_time);
-            store(prim_boxes_out + 6 * k, b.lo);
-            store(prim_boxes_out + 6 * k + 3, b.hi);
+            store(prim_boxes_out + 6 * k, boxes[k].lo);
+            store(prim_boxes_out + 6 * k + 3, boxes[k].hi);
         }
+    }
     return RT_OK;
 }
 
@@ -309,12 +324,16 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     sc->n_shapes = desc->n_shapes;
     sc->width = desc->camera.resolution_x;
     sc->height = desc->camera.resolution_y;
+    BuildClock clock;
     sc->bvh = build_bvh(*desc);
+    clock.lap("reference-order tree");
     sc->trav = traversal_tree(*desc, sc->bvh);
+    clock.lap("traversal tree");
     // A 4-wide node defers at most three children per level, and the collapsed tree is never deeper than the binary one.
     if (3 * sc->trav.max_depth > kTravStackDepth)
         return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + " entries)");
     HostArrays h = derive_arrays(*desc, sc->bvh);
+    clock.lap("primitive arrays");
 
     DScene& d = sc->d;
     auto track = [&](void* p) { if (p) sc->allocations.push_back(p); };
@@ -324,6 +343,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     };
     DNode4* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
     Bvh4 b32 = device_image(*desc, sc->trav);
+    clock.lap("4-wide image");
     sc->n_nodes4 = static_cast<int32_t>(b32.nodes.size());
     sc->depth4 = b32.max_depth;
     if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
@@ -352,6 +372,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         if (e == hipSuccess) { track(d_env); e = hipMemcpy(d_env, desc->env.rgb, bytes, hipMemcpyHostToDevice); }
         if (e != hipSuccess) return cleanup_fail(fail(RT_ERR_DEVICE, std::string("environment upload: ") + hipGetErrorString(e)));
     }
+    clock.lap("upload");
     d.nodes = d_nodes; d.prims = d_prims; d.file_order = d_forder; d.xforms = d_x; d.quads = d_q;
     d.materials = d_m; d.textures = d_tex; d.lights = d_l; d.env = d_env;
     d.env_present = desc->env.present ? 1 : 0;

@@ -1,11 +1,69 @@
 #include "host_bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <numeric>
+#include <thread>
+#include <unordered_map>
 
 namespace rt {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host threads.  All three passes below (reference-order tree, traversal tree, 4-wide collapse) are top-down
+// recursions over disjoint index ranges whose output positions are known before a subtree is built, so a step over
+// many primitives hands one half to another thread.  Results do not depend on the number of threads.
+namespace {
+
+int build_threads() {
+    if (const char* e = std::getenv("RT_BUILD_THREADS")) return std::max(1, std::atoi(e));
+    // hardware_concurrency() is the whole machine, not this process's share of it: stay modest
+    return static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+}
+
+class Tasks {
+    std::atomic<int> free_;
+
+public:
+    explicit Tasks(int threads) : free_(threads - 1) {}
+    bool acquire() {
+        int v = free_.load();
+        while (v > 0)
+            if (free_.compare_exchange_weak(v, v - 1)) return true;
+        return false;
+    }
+    void release() { free_.fetch_add(1); }
+};
+constexpr size_t kTaskGrain = 8192;   // primitives below which a subtree is not worth a thread
+
+template <class L, class R>
+void fork_join(Tasks& tasks, bool big, L&& left, R&& right) {
+    if (big && tasks.acquire()) {
+        std::thread th([&] { left(); });
+        right();
+        th.join();
+        tasks.release();
+    } else {
+        left();
+        right();
+    }
+}
+
+template <class F>
+void parallel_for(size_t n, F&& body) {   // body(begin, end)
+    const size_t threads = std::min<size_t>(static_cast<size_t>(build_threads()), std::max<size_t>(1, n / kTaskGrain));
+    if (threads <= 1) { body(size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < threads; ++t) pool.emplace_back([&, t] { body(n * t / threads, n * (t + 1) / threads); });
+    body(size_t(0), n / threads);
+    for (std::thread& th : pool) th.join();
+}
+
+}  // namespace
 
 static Box transformed_box(const RtShape& s, V3 lmin, V3 lmax, double shutter_time) {
     const double inf = std::numeric_limits<double>::infinity();
@@ -69,8 +127,10 @@ namespace {
 struct Builder {
     const std::vector<Box>& boxes;
     std::vector<V3> centre;          // (lo+hi)*0.5, the sort key of bvh.cpp:14-15
-    std::vector<int32_t> idx;        // working permutation of shape indices
+    std::vector<int32_t> idx;        // working permutation of shape indices; the depth-first leaf order when build() is done
     HostBvh out;
+    Tasks tasks{build_threads()};
+    std::unordered_map<size_t, size_t> node_count;   // interior nodes of a subtree over n shapes (filled before build())
 
     struct Built {
         int32_t ref;
@@ -80,9 +140,20 @@ struct Builder {
 
     bool less_on(int axis, int32_t a, int32_t b) const { return centre[a][axis] < centre[b][axis]; }
 
-    // One reference BVHNode over idx[start, end).  Nodes whose two children are shapes become leaf references;
-    // everything else becomes a DNode carrying its children's boxes.
-    Built build(size_t start, size_t end) {
+    // The split sizes depend on n only (bvh.cpp:60-78), so the nodes of a subtree occupy a known range of out.nodes
+    // (depth-first: node, left subtree, right subtree) and its leaves the range [start, end) of the order.
+    size_t count_nodes(size_t n) {
+        if (n <= 2) return 0;
+        auto it = node_count.find(n);
+        if (it != node_count.end()) return it->second;
+        const size_t c = 1 + count_nodes(n / 2) + count_nodes(n - n / 2);
+        node_count.emplace(n, c);
+        return c;
+    }
+
+    // One reference BVHNode over idx[start, end), stored at out.nodes[me].  Nodes whose two children are shapes become
+    // leaf references; everything else becomes a DNode carrying its children's boxes.
+    Built build(size_t start, size_t end, size_t me) {
         Box span = boxes[idx[start]];
         for (size_t i = start + 1; i < end; ++i) span = combine(span, boxes[idx[i]]);
         V3 ext = span.hi - span.lo;
@@ -91,33 +162,28 @@ struct Builder {
         else if (ext.z > ext.x && ext.z > ext.y) axis = 2;
 
         size_t n = end - start;
-        if (n == 1) {  // left == right == the single shape
-            int32_t first = static_cast<int32_t>(out.order.size());
-            out.order.push_back(idx[start]);
-            return {make_leaf_ref(first, 1), boxes[idx[start]], 0};
-        }
+        if (n == 1)  // left == right == the single shape
+            return {make_leaf_ref(static_cast<int32_t>(start), 1), boxes[idx[start]], 0};
         if (n == 2) {  // ordered pair (bvh.cpp:67-75)
             int32_t a = idx[start], b = idx[start + 1];
             if (!less_on(axis, a, b)) std::swap(a, b);
-            int32_t first = static_cast<int32_t>(out.order.size());
-            out.order.push_back(a);
-            out.order.push_back(b);
-            return {make_leaf_ref(first, 2), combine(boxes[a], boxes[b]), 0};
+            idx[start] = a;
+            idx[start + 1] = b;
+            return {make_leaf_ref(static_cast<int32_t>(start), 2), combine(boxes[a], boxes[b]), 0};
         }
         size_t mid = start + n / 2;
         std::nth_element(idx.begin() + start, idx.begin() + mid, idx.begin() + end,
                          [&](int32_t a, int32_t b) { return less_on(axis, a, b); });
-        int32_t me = static_cast<int32_t>(out.nodes.size());
-        out.nodes.emplace_back();
-        Built l = build(start, mid);
-        Built r = build(mid, end);
+        Built l, r;
+        const size_t left_nodes = node_count.count(mid - start) ? node_count.at(mid - start) : 0;
+        fork_join(tasks, n > kTaskGrain, [&] { l = build(start, mid, me + 1); }, [&] { r = build(mid, end, me + 1 + left_nodes); });
         DNode& nd = out.nodes[me];
         store(nd.lo[0], l.box.lo); store(nd.hi[0], l.box.hi);
         store(nd.lo[1], r.box.lo); store(nd.hi[1], r.box.hi);
         nd.child[0] = l.ref;
         nd.child[1] = r.ref;
         for (int& p : nd.pad) p = 0;
-        return {me, combine(l.box, r.box), 1 + std::max(l.depth, r.depth)};
+        return {static_cast<int32_t>(me), combine(l.box, r.box), 1 + std::max(l.depth, r.depth)};
     }
 };
 
@@ -143,10 +209,12 @@ inline int ceil_log2(size_t n) {
 
 struct SahBuilder {
     static constexpr int kBins = 32;
+    static constexpr size_t kWideStep = size_t(1) << 17;
     const std::vector<Box>& boxes;   // per primitive, indexed by reference depth-first order
     std::vector<V3> centre;
     std::vector<int32_t> idx;
     HostBvh out;
+    Tasks tasks{build_threads()};
 
     struct Built {
         int32_t ref;
@@ -155,29 +223,81 @@ struct SahBuilder {
     };
 
     // depth_left = interior levels this subtree may use; callers guarantee ceil_log2(n) <= depth_left.
-    Built build(size_t start, size_t end, int depth_left) {
+    // A subtree over n primitives has n - 1 interior nodes: they go to out.nodes[me, me + n - 1), depth-first.
+    Built build(size_t start, size_t end, int depth_left, size_t me) {
         const size_t n = end - start;
         if (n == 1) return {make_leaf_ref(idx[start], 1), boxes[idx[start]], 0};
         const double inf = std::numeric_limits<double>::infinity();
-        Box cb{{inf, inf, inf}, {-inf, -inf, -inf}};
-        for (size_t i = start; i < end; ++i) grow(cb, centre[idx[i]]);
+        const Box empty{{inf, inf, inf}, {-inf, -inf, -inf}};
+        const bool wide = n >= kWideStep;   // near the root there are fewer subtrees than threads: split the passes over the range instead
+        Box cb = empty;
+        if (wide) {
+            std::mutex m;
+            parallel_for(n, [&](size_t b0, size_t e0) {
+                Box part = empty;
+                for (size_t i = start + b0; i < start + e0; ++i) grow(part, centre[idx[i]]);
+                std::lock_guard<std::mutex> g(m);
+                cb = combine(cb, part);
+            });
+        } else {
+            for (size_t i = start; i < end; ++i) grow(cb, centre[idx[i]]);
+        }
         size_t mid = start + n / 2;
         bool split_done = false;
         if (n > 2) {
+            // bins of all three axes in one pass over the primitives (min / max / counts: the order does not matter)
+            struct Bins {
+                Box bb[3][kBins];
+                size_t cnt[3][kBins];
+            };
+            double lo3[3], scale3[3];
+            bool use[3];
+            for (int axis = 0; axis < 3; ++axis) {
+                const double ext = cb.hi[axis] - cb.lo[axis];
+                use[axis] = ext > 0.0 && std::isfinite(ext);
+                lo3[axis] = cb.lo[axis];
+                scale3[axis] = use[axis] ? kBins / ext : 0.0;
+            }
+            auto clear = [&](Bins& B) {
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int b = 0; b < kBins; ++b) { B.bb[axis][b] = empty; B.cnt[axis][b] = 0; }
+            };
+            auto fill = [&](Bins& B, size_t b0, size_t e0) {
+                for (size_t i = b0; i < e0; ++i) {
+                    const int32_t p = idx[i];
+                    const Box& pb = boxes[p];
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (!use[axis]) continue;
+                        int b = std::min(kBins - 1, std::max(0, static_cast<int>((centre[p][axis] - lo3[axis]) * scale3[axis])));
+                        B.bb[axis][b] = combine(B.bb[axis][b], pb);
+                        ++B.cnt[axis][b];
+                    }
+                }
+            };
+            Bins bins;
+            clear(bins);
+            if (wide) {
+                std::mutex m;
+                parallel_for(n, [&](size_t b0, size_t e0) {
+                    auto part = std::make_unique<Bins>();
+                    clear(*part);
+                    fill(*part, start + b0, start + e0);
+                    std::lock_guard<std::mutex> g(m);
+                    for (int axis = 0; axis < 3; ++axis)
+                        for (int b = 0; b < kBins; ++b) {
+                            bins.bb[axis][b] = combine(bins.bb[axis][b], part->bb[axis][b]);
+                            bins.cnt[axis][b] += part->cnt[axis][b];
+                        }
+                });
+            } else {
+                fill(bins, start, end);
+            }
             double best_cost = inf;
             int best_axis = -1, best_bin = -1;
             for (int axis = 0; axis < 3; ++axis) {
-                const double lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
-                if (!(ext > 0.0) || !std::isfinite(ext)) continue;
-                const double scale = kBins / ext;
-                Box bb[kBins];
-                size_t cnt[kBins];
-                for (int b = 0; b < kBins; ++b) { bb[b] = Box{{inf, inf, inf}, {-inf, -inf, -inf}}; cnt[b] = 0; }
-                for (size_t i = start; i < end; ++i) {
-                    int b = std::min(kBins - 1, std::max(0, static_cast<int>((centre[idx[i]][axis] - lo) * scale)));
-                    bb[b] = combine(bb[b], boxes[idx[i]]);
-                    ++cnt[b];
-                }
+                if (!use[axis]) continue;
+                const Box* bb = bins.bb[axis];
+                const size_t* cnt = bins.cnt[axis];
                 double right_area[kBins];
                 size_t right_cnt[kBins];
                 Box acc{{inf, inf, inf}, {-inf, -inf, -inf}};
@@ -220,36 +340,39 @@ struct SahBuilder {
                 return centre[a][axis] < centre[b][axis] || (centre[a][axis] == centre[b][axis] && a < b);
             });
         }
-        int32_t me = static_cast<int32_t>(out.nodes.size());
-        out.nodes.emplace_back();
-        Built l = build(start, mid, depth_left - 1);
-        Built r = build(mid, end, depth_left - 1);
+        Built l, r;
+        fork_join(tasks, n > kTaskGrain, [&] { l = build(start, mid, depth_left - 1, me + 1); },
+                  [&] { r = build(mid, end, depth_left - 1, me + (mid - start)); });
         DNode& nd = out.nodes[me];
         store(nd.lo[0], l.box.lo); store(nd.hi[0], l.box.hi);
         store(nd.lo[1], r.box.lo); store(nd.hi[1], r.box.hi);
         nd.child[0] = l.ref;
         nd.child[1] = r.ref;
         for (int& p : nd.pad) p = 0;
-        return {me, combine(l.box, r.box), 1 + std::max(l.depth, r.depth)};
+        return {static_cast<int32_t>(me), combine(l.box, r.box), 1 + std::max(l.depth, r.depth)};
     }
 };
 
 }  // namespace
 
 HostBvh build_traversal_bvh(const std::vector<Box>& boxes, int max_depth) {
-    SahBuilder b{boxes, {}, {}, {}};
+    SahBuilder b{boxes};
     const size_t n = boxes.size();
     if (n == 0) {
         b.out.root_ref = make_leaf_ref(0, 1);
         b.out.root_box = Box{};
-        return b.out;
+        return std::move(b.out);
     }
     b.centre.resize(n);
-    for (size_t i = 0; i < n; ++i) b.centre[i] = (boxes[i].lo + boxes[i].hi) * 0.5;
     b.idx.resize(n);
-    std::iota(b.idx.begin(), b.idx.end(), 0);
-    b.out.nodes.reserve(n);
-    SahBuilder::Built root = b.build(0, n, std::max(max_depth, ceil_log2(n)));
+    parallel_for(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            b.centre[i] = (boxes[i].lo + boxes[i].hi) * 0.5;
+            b.idx[i] = static_cast<int32_t>(i);
+        }
+    });
+    b.out.nodes.resize(n - 1);
+    SahBuilder::Built root = b.build(0, n, std::max(max_depth, ceil_log2(n)), 0);
     b.out.root_ref = root.ref;
     b.out.root_box = root.box;
     b.out.max_depth = root.depth;
@@ -273,17 +396,19 @@ struct Collapser {
     const HostBvh& bvh;
     double pad;
     Bvh4& out;
+    std::vector<int32_t> wide_count;   // per binary node that roots a 4-wide node: 4-wide nodes of its subtree (pass 1)
+    Tasks tasks{build_threads()};
+    static constexpr int kForkLevels = 4;   // 4-wide levels from the root whose children may go to other threads
 
     struct Slot {
         int32_t ref;
         Box box;
     };
 
-    // One 4-wide node for the binary subtree rooted at interior node b; returns its index and depth (levels).
-    std::pair<int32_t, int32_t> emit(int32_t b) {
-        const int32_t me = static_cast<int32_t>(out.nodes.size());
-        out.nodes.emplace_back();
+    // The children of the 4-wide node rooted at binary interior node b.
+    std::vector<Slot> open(int32_t b) const {
         std::vector<Slot> slots;
+        slots.reserve(4);
         auto children_of = [&](int32_t n, Slot& l, Slot& r) {
             const DNode& nd = bvh.nodes[n];
             l = Slot{nd.child[0], Box{V3(nd.lo[0]), V3(nd.hi[0])}};
@@ -306,19 +431,43 @@ struct Collapser {
             slots[pick] = l;
             slots.push_back(r);
         }
-        int32_t depth = 1;
+        return slots;
+    }
+
+    template <class F>
+    void for_children(const std::vector<Slot>& slots, int level, F&& f) {   // f(i) for every slot, the two halves on two threads near the root
+        const size_t h = slots.size() / 2;
+        fork_join(tasks, level < kForkLevels,
+                  [&] { for (size_t i = 0; i < h; ++i) f(i); },
+                  [&] { for (size_t i = h; i < slots.size(); ++i) f(i); });
+    }
+
+    // Pass 1: number of 4-wide nodes below (and including) the one rooted at b, so that pass 2 knows where every
+    // subtree goes (depth-first: node, then the subtrees of its children in slot order).
+    int32_t count(int32_t b, int level) {
+        const std::vector<Slot> slots = open(b);
+        int32_t sub[4] = {0, 0, 0, 0};
+        for_children(slots, level, [&](size_t i) { if (slots[i].ref >= 0) sub[i] = count(slots[i].ref, level + 1); });
+        return wide_count[b] = 1 + sub[0] + sub[1] + sub[2] + sub[3];
+    }
+
+    // Pass 2: the 4-wide node for the binary subtree rooted at interior node b, written to out.nodes[me]; returns its depth (levels).
+    int32_t emit(int32_t b, int32_t me, int level) {
+        const std::vector<Slot> slots = open(b);
         int32_t refs[4] = {kEmptyChild, kEmptyChild, kEmptyChild, kEmptyChild};
+        int32_t depths[4] = {0, 0, 0, 0};
+        int32_t next = me + 1;
         for (size_t i = 0; i < slots.size(); ++i) {
             if (slots[i].ref >= 0) {
-                auto sub = emit(slots[i].ref);
-                refs[i] = sub.first;
-                depth = std::max(depth, 1 + sub.second);
+                refs[i] = next;
+                next += wide_count[slots[i].ref];
             } else {
                 refs[i] = slots[i].ref;
             }
         }
+        for_children(slots, level, [&](size_t i) { if (slots[i].ref >= 0) depths[i] = emit(slots[i].ref, refs[i], level + 1); });
         quantise(out.nodes[me], slots, refs);
-        return {me, depth};
+        return 1 + std::max(std::max(depths[0], depths[1]), std::max(depths[2], depths[3]));
     }
 
     void quantise(DNode4& o, const std::vector<Slot>& slots, const int32_t refs[4]) const {
@@ -390,11 +539,11 @@ Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin) {
     out.root_ref = bvh.root_ref;
     out.max_depth = 0;
     if (!bvh.nodes.empty() && bvh.root_ref >= 0) {
-        out.nodes.reserve(bvh.nodes.size() / 2 + 16);
         Collapser c{bvh, out.pad, out};
-        auto root = c.emit(bvh.root_ref);
-        out.root_ref = root.first;
-        out.max_depth = root.second;
+        c.wide_count.assign(bvh.nodes.size(), 0);
+        out.nodes.resize(static_cast<size_t>(c.count(bvh.root_ref, 0)));
+        out.max_depth = c.emit(bvh.root_ref, 0, 0);
+        out.root_ref = 0;
     }
     for (int a = 0; a < 3; ++a) {
         out.root_lo[a] = round_down(rl[a] - out.pad);
@@ -403,22 +552,35 @@ Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin) {
     return out;
 }
 
+std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order) {
+    const size_t n = static_cast<size_t>(std::max(desc.n_shapes, 0));
+    std::vector<Box> boxes(n);
+    parallel_for(n, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) boxes[i] = shape_bounds(desc.shapes[order ? order[i] : static_cast<int32_t>(i)], desc.shutter_time);
+    });
+    return boxes;
+}
+
 HostBvh build_bvh(const RtSceneDesc& desc) {
-    std::vector<Box> boxes(desc.n_shapes);
-    for (int i = 0; i < desc.n_shapes; ++i) boxes[i] = shape_bounds(desc.shapes[i], desc.shutter_time);
-    Builder b{boxes, {}, {}, {}};
-    if (desc.n_shapes == 0) {
+    const size_t n = static_cast<size_t>(std::max(desc.n_shapes, 0));
+    const std::vector<Box> boxes = shape_boxes(desc, nullptr);
+    Builder b{boxes};
+    if (n == 0) {
         b.out.root_ref = make_leaf_ref(0, 1);
         b.out.root_box = Box{};
-        return b.out;
+        return std::move(b.out);
     }
-    b.centre.resize(desc.n_shapes);
-    for (int i = 0; i < desc.n_shapes; ++i) b.centre[i] = (boxes[i].lo + boxes[i].hi) * 0.5;
-    b.idx.resize(desc.n_shapes);
-    std::iota(b.idx.begin(), b.idx.end(), 0);
-    b.out.nodes.reserve(desc.n_shapes);
-    b.out.order.reserve(desc.n_shapes);
-    Builder::Built root = b.build(0, desc.n_shapes);
+    b.centre.resize(n);
+    b.idx.resize(n);
+    parallel_for(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            b.centre[i] = (boxes[i].lo + boxes[i].hi) * 0.5;
+            b.idx[i] = static_cast<int32_t>(i);
+        }
+    });
+    b.out.nodes.resize(b.count_nodes(n));
+    Builder::Built root = b.build(0, n, 0);
+    b.out.order = std::move(b.idx);
     b.out.root_ref = root.ref;
     b.out.root_box = root.box;
     b.out.max_depth = root.depth;

@@ -20,6 +20,8 @@ struct HostBvh {
 // World-space box of one shape at build time (transformed_shape.h:42-77, plane.cpp:11-46,
 // complex_sphere.cpp:21-27, complex_cube.cpp:25-31, complex_plane.cpp:24-75).
 Box shape_bounds(const RtShape& s, double shutter_time);
+// The boxes of all shapes (host threads); box k belongs to shape order[k], or to shape k when order is NULL.
+std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order);
 
 // Device image of the hierarchy: the binary tree collapsed to four children per node with 8-bit quantised child
 // boxes (device_types.h: DNode4).  Every box is first moved outward by an absolute pad that covers the FP32 rounding of
@@ -39,6 +41,8 @@ Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin);
 // interior levels (the per-lane traversal stack), falling back to balanced splits where the bound is tight.
 HostBvh build_traversal_bvh(const std::vector<Box>& boxes, int max_depth);
 
+// All three builders run their subtrees on up to RT_BUILD_THREADS host threads (default: min(16, cores)); their
+// results do not depend on the number of threads.
 // n_shapes == 0 yields an empty hierarchy (root_ref is a leaf of zero primitives; callers must check).
 HostBvh build_bvh(const RtSceneDesc& desc);
 
