@@ -232,6 +232,28 @@ int rt_bvh_build_host(const RtSceneDesc* desc, RtBvhInfo* info_out, int32_t* ord
 int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_nodes, RtBvhInfo* info_out, int32_t* root_ref_out,
                         double* pad_out, double* prim_boxes_out);
 
+/* Which builder rt_scene_create uses for the hierarchy the device traverses (process-wide, for scenes created
+ * afterwards).  The primitive numbering -- the reference's depth-first visit order (bvh.cpp:32-92), which decides
+ * equal-distance hits -- always comes from the host pass; the closest hit does not depend on the hierarchy, so all
+ * builders yield the same frames.
+ *   RT_BVH_SAH     binned surface-area heuristic on host threads (default; fewest node visits per ray)
+ *   RT_BVH_LBVH    built on the GPU: Morton order, radix sort, binary radix tree, bottom-up boxes, 4-wide collapse and
+ *                  8-bit quantisation in HIP kernels.  Milliseconds for 10^6 shapes; falls back
+ *                  to RT_BVH_SAH when the tree would be deeper than the traversal stack (32 4-wide levels).
+ *   RT_BVH_MEDIAN  the reference's own topology (A/B runs)
+ *   RT_BVH_DEFAULT environment variable RT_BVH_BUILDER = sah | lbvh | median, else SAH
+ * The reference has one builder, on the host (bvh.cpp:32-92). */
+#define RT_BVH_DEFAULT -1
+#define RT_BVH_SAH      0
+#define RT_BVH_LBVH     1
+#define RT_BVH_MEDIAN   2
+int rt_set_bvh_builder(int builder);
+/* The node array of a device scene copied back to the host (layout: rt_bvh_device_image), for tests of the device
+ * builder.  nodes_out: room for max_nodes nodes or NULL; the other outputs may be NULL: root reference, outward pad,
+ * the builder that actually built the hierarchy (RT_BVH_*) and, for RT_BVH_LBVH, the device time of the build in ms. */
+int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, int32_t* root_ref_out, double* pad_out,
+                       int32_t* builder_out, double* device_build_ms_out);
+
 /* ---- render ------------------------------------------------------------------------------------ */
 
 /* Whole-frame render into a caller-owned host buffer rgb8_out[H*W*3], row-major, top row first — the bytes of

@@ -113,6 +113,7 @@ ABI_SYMBOLS = [
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
     "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
+    "rt_set_bvh_builder", "rt_scene_bvh_nodes",
 ]
 
 
@@ -155,6 +156,9 @@ def _load():
         "rt_write_pfm": (i32, [cp, i32, i32, vp]),
         "rt_bvh_device_image": (i32, [C.POINTER(RtSceneDesc), vp, C.c_int32, C.POINTER(RtBvhInfo), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_double), vp]),
+        "rt_set_bvh_builder": (i32, [i32]),
+        "rt_scene_bvh_nodes": (i32, [vp, vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_double)]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
         "rt_part_rows": (i32, [i32, i32, i32, i32]),
@@ -198,6 +202,15 @@ def init(device_id=-1):
 
 def shutdown():
     lib.rt_shutdown()
+
+
+BVH_BUILDERS = {"default": -1, "sah": 0, "lbvh": 1, "median": 2}   # RT_BVH_* of rt_mi355x.h
+
+
+def set_bvh_builder(name):
+    """Builder of the hierarchy the device traverses, for scenes created afterwards: "sah" (host threads, default),
+    "lbvh" (built on the GPU), "median" (the reference's topology), "default" (environment RT_BVH_BUILDER, else sah)."""
+    _check(lib.rt_set_bvh_builder(BVH_BUILDERS[name]))
 
 
 # ---------------------------------------------------------------------------------------- Config (config.cpp)
@@ -408,6 +421,17 @@ class Scene:
         info = RtBvhInfo()
         _check(lib.rt_scene_bvh_info(self._h, C.byref(info)))
         return info
+
+    def bvh_nodes(self):
+        """The hierarchy as it lies in device memory: dict with `nodes` (NODE4_DTYPE), `root_ref`, `pad`, `builder` (name of
+        the builder that actually built it) and `device_build_ms` (lbvh only)."""
+        info = self.bvh_info()
+        nodes = np.zeros(max(1, info.n_nodes), dtype=NODE4_DTYPE)
+        root, pad, builder, ms = C.c_int32(0), C.c_double(0.0), C.c_int32(0), C.c_double(0.0)
+        _check(lib.rt_scene_bvh_nodes(self._h, nodes.ctypes.data, len(nodes), C.byref(root), C.byref(pad), C.byref(builder), C.byref(ms)))
+        names = {v: k for k, v in BVH_BUILDERS.items()}
+        return {"nodes": nodes[: info.n_nodes], "info": info, "root_ref": root.value, "pad": pad.value, "builder": names[builder.value],
+                "device_build_ms": ms.value}
 
     def render(self, params, stats=False):
         """One frame -> uint8 [H, W, 3] (the bytes Image::write would store).  stats=True also returns RtStats."""

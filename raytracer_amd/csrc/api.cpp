@@ -17,6 +17,7 @@
 
 #include "../../include/rt_mi355x.h"
 #include "device_types.h"
+#include "bvh_build.h"
 #include "host_bvh.h"
 #include "host_config.h"
 #include "host_image.h"
@@ -65,6 +66,9 @@ struct rt_scene_s {
     HostBvh trav;                     // what the device traverses (host_bvh.h: build_traversal_bvh)
     int n_shapes = 0;
     int32_t n_nodes4 = 0, depth4 = 0;   // the 4-wide device image of trav
+    int builder = RT_BVH_SAH;         // what built the device image (RT_BVH_*)
+    double node_pad = 0;              // outward pad of its boxes
+    double build_ms = 0;              // RT_BVH_LBVH: device time of the build
     int width = 0, height = 0;
     DScene d{};                       // device view (pointers are device pointers)
     std::vector<void*> allocations;   // everything to hipFree
@@ -213,16 +217,28 @@ struct BuildClock {
     }
 };
 
+// Builder of the hierarchy the device traverses: rt_set_bvh_builder(), else RT_BVH_BUILDER = sah | lbvh | median, else SAH.
+static int g_builder = -1;
+static int chosen_builder() {
+    if (g_builder >= 0) return g_builder;
+    const char* e = std::getenv("RT_BVH_BUILDER");
+    if (e && std::string(e) == "median") return RT_BVH_MEDIAN;
+    if (e && std::string(e) == "lbvh") return RT_BVH_LBVH;
+    return RT_BVH_SAH;
+}
+static double max_camera_coordinate(const RtSceneDesc& desc) {
+    double m = 0.0;
+    for (int a = 0; a < 3; ++a) m = std::max(m, std::fabs(desc.camera.location[a]));
+    return m;
+}
+
 // The hierarchy the device traverses, from the reference-topology tree that fixes the primitive order.
 static HostBvh traversal_tree(const RtSceneDesc& desc, const HostBvh& ref) {
-    const char* e = std::getenv("RT_BVH_BUILDER");   // "median": traverse the reference topology itself (A/B runs)
-    if (e && std::string(e) == "median") return ref;
+    if (chosen_builder() == RT_BVH_MEDIAN) return ref;   // traverse the reference topology itself (A/B runs)
     return build_traversal_bvh(shape_boxes(desc, ref.order.data()), kMaxBinaryDepth);
 }
 static Bvh4 device_image(const RtSceneDesc& desc, const HostBvh& trav) {
-    double max_origin = 0.0;
-    for (int a = 0; a < 3; ++a) max_origin = std::max(max_origin, std::fabs(desc.camera.location[a]));
-    return to_node4(trav, max_origin);
+    return to_node4(trav, max_camera_coordinate(desc));
 }
 
 extern "C" {
@@ -327,11 +343,47 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     BuildClock clock;
     sc->bvh = build_bvh(*desc);
     clock.lap("reference-order tree");
-    sc->trav = traversal_tree(*desc, sc->bvh);
-    clock.lap("traversal tree");
-    // A 4-wide node defers at most three children per level, and the collapsed tree is never deeper than the binary one.
-    if (3 * sc->trav.max_depth > kTravStackDepth)
-        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + " entries)");
+    // The hierarchy the device traverses: built on the GPU (RT_BVH_LBVH) or on host threads.
+    DNode4* d_nodes = nullptr;
+    Bvh4 b32;
+    sc->builder = chosen_builder();
+    if (sc->builder == RT_BVH_LBVH && desc->n_shapes >= 2) {
+        const std::vector<Box> boxes = shape_boxes(*desc, sc->bvh.order.data());
+        clock.lap("primitive boxes");
+        DeviceBvh4 dev4;
+        hipError_t herr = hipSuccess;
+        const LbvhStatus st = build_lbvh_device(boxes, sc->bvh.root_box, max_camera_coordinate(*desc), g_dev.stream, &dev4, &herr);
+        clock.lap("device LBVH (with upload)");
+        if (st == LbvhStatus::device_error) return fail(RT_ERR_DEVICE, std::string("device BVH build: ") + hipGetErrorString(herr));
+        if (st == LbvhStatus::ok) {
+            d_nodes = dev4.nodes;
+            sc->allocations.push_back(d_nodes);
+            b32.root_ref = dev4.root_ref;
+            b32.max_depth = dev4.max_depth;
+            b32.pad = dev4.pad;
+            for (int a = 0; a < 3; ++a) { b32.root_lo[a] = dev4.root_lo[a]; b32.root_hi[a] = dev4.root_hi[a]; }
+            sc->n_nodes4 = dev4.n_nodes;
+            sc->build_ms = dev4.build_ms;
+            sc->trav.root_box = sc->bvh.root_box;
+            sc->trav.root_ref = 0;
+        } else {
+            sc->builder = RT_BVH_SAH;   // deeper than the traversal stack: the host builder bounds its depth
+        }
+    } else if (sc->builder == RT_BVH_LBVH) {
+        sc->builder = RT_BVH_SAH;       // fewer than two shapes: nothing to build
+    }
+    if (!d_nodes) {
+        sc->trav = traversal_tree(*desc, sc->bvh);
+        clock.lap("traversal tree");
+        // A 4-wide node defers at most three children per level, and the collapsed tree is never deeper than the binary one.
+        if (3 * sc->trav.max_depth > kTravStackDepth)
+            return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(sc->trav.max_depth) + " exceeds the traversal stack (" + std::to_string(kTravStackDepth) + " entries)");
+        b32 = device_image(*desc, sc->trav);
+        clock.lap("4-wide image");
+        sc->n_nodes4 = static_cast<int32_t>(b32.nodes.size());
+    }
+    sc->depth4 = b32.max_depth;
+    sc->node_pad = b32.pad;
     HostArrays h = derive_arrays(*desc, sc->bvh);
     clock.lap("primitive arrays");
 
@@ -341,12 +393,11 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         for (void* p : sc->allocations) (void)hipFree(p);
         return code;
     };
-    DNode4* d_nodes; DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
-    Bvh4 b32 = device_image(*desc, sc->trav);
-    clock.lap("4-wide image");
-    sc->n_nodes4 = static_cast<int32_t>(b32.nodes.size());
-    sc->depth4 = b32.max_depth;
-    if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc); track(d_nodes);
+    DPrim* d_prims; int32_t* d_forder; DXform* d_x; DQuad* d_q; DMaterial* d_m; DLight* d_l;
+    if (!b32.nodes.empty()) {
+        if ((rc = upload(b32.nodes, &d_nodes))) return cleanup_fail(rc);
+        track(d_nodes);
+    }
     if ((rc = upload(h.prims, &d_prims))) return cleanup_fail(rc); track(d_prims);
     if ((rc = upload(h.file_order, &d_forder))) return cleanup_fail(rc); track(d_forder);
     if ((rc = upload(h.xforms, &d_x))) return cleanup_fail(rc); track(d_x);
@@ -402,6 +453,30 @@ void rt_scene_destroy(rt_scene_t scene) {
         for (auto& kv : scene->wf) wavefront_workspace_free(kv.second);
     }
     delete scene;
+}
+
+int rt_set_bvh_builder(int builder) {
+    if (builder != RT_BVH_DEFAULT && builder != RT_BVH_SAH && builder != RT_BVH_LBVH && builder != RT_BVH_MEDIAN)
+        return fail(RT_ERR_INVALID, "unknown BVH builder");
+    g_builder = builder;
+    return RT_OK;
+}
+
+int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, int32_t* root_ref_out, double* pad_out, int32_t* builder_out,
+                       double* device_build_ms_out) {
+    if (!scene) return fail(RT_ERR_INVALID, "NULL argument");
+    if (root_ref_out) *root_ref_out = scene->d.root_ref;
+    if (pad_out) *pad_out = scene->node_pad;
+    if (builder_out) *builder_out = scene->builder;
+    if (device_build_ms_out) *device_build_ms_out = scene->build_ms;
+    if (nodes_out) {
+        if (max_nodes < scene->n_nodes4) return fail(RT_ERR_LIMIT, "nodes_out is too small");
+        if (scene->n_nodes4 > 0) {
+            HIP_TRY(hipSetDevice(g_dev.device));
+            HIP_TRY(hipMemcpy(nodes_out, scene->d.nodes, static_cast<size_t>(scene->n_nodes4) * sizeof(DNode4), hipMemcpyDeviceToHost));
+        }
+    }
+    return RT_OK;
 }
 
 int rt_scene_bvh_info(rt_scene_t scene, RtBvhInfo* out) {

@@ -1,0 +1,36 @@
+// GPU build of the hierarchy the device traverses: a linear BVH over Morton-ordered primitive
+// boxes, collapsed and quantised on the device into the same 4-wide 64-byte nodes the host builder produces
+// (device_types.h: DNode4; host_bvh.cpp: to_node4).  The reference builds its tree on the host only
+// (Code/acceleration/bvh.cpp:32-92); the primitive numbering -- the reference's depth-first visit order, which the
+// tie rule of device_rt.h needs -- still comes from the host pass (host_bvh.cpp: build_bvh).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "device_types.h"
+#include "host_math.h"
+
+namespace rt {
+
+struct DeviceBvh4 {
+    DNode4* nodes = nullptr;   // device memory (hipMalloc); owned by the caller after LbvhStatus::ok
+    int32_t n_nodes = 0;
+    int32_t root_ref = 0;
+    int32_t max_depth = 0;     // 4-wide levels
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    double pad = 0;
+    float build_ms = 0;        // device time from the first kernel to the last (upload excluded)
+};
+
+enum class LbvhStatus {
+    ok,
+    too_deep,       // more 4-wide levels than the traversal stack allows: the caller falls back to the host builder
+    device_error    // *err holds the HIP error
+};
+
+// boxes: one per primitive, in primitive order (n >= 2); root_box: their union; max_abs_origin: as for to_node4.
+LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box, double max_abs_origin, hipStream_t stream,
+                             DeviceBvh4* out, hipError_t* err);
+
+}  // namespace rt

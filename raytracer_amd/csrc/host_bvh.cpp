@@ -355,6 +355,28 @@ struct SahBuilder {
 
 }  // namespace
 
+double node4_pad(const Box& root_box, double max_abs_origin) {
+    double m = max_abs_origin;
+    auto grow_abs = [&](V3 p) { for (int a = 0; a < 3; ++a) if (std::isfinite(p[a])) m = std::max(m, std::fabs(p[a])); };
+    grow_abs(root_box.lo);
+    grow_abs(root_box.hi);
+    // Absolute FP32 errors of the device slab test (device_rt.h: node4_test), in world units, for coordinates bounded
+    // by m: rounding the ray origin (2^-24 m), the product o*inv (2^-24 m), org*inv - o*inv (2^-23 m) -- under
+    // 5 * 2^-24 m in total.  Ray origins are the camera or surface points inside the root box moved by at most ~1e-3
+    // (tracer.h:201, shading.h:68,93).  Relative errors are covered on the device.
+    return (m + 0.01) * std::ldexp(1.0, -21);
+}
+float round_down(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+float round_up(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
 HostBvh build_traversal_bvh(const std::vector<Box>& boxes, int max_depth) {
     SahBuilder b{boxes};
     const size_t n = boxes.size();
@@ -377,17 +399,6 @@ HostBvh build_traversal_bvh(const std::vector<Box>& boxes, int max_depth) {
     b.out.root_box = root.box;
     b.out.max_depth = root.depth;
     return std::move(b.out);
-}
-
-static float round_down(double v) {
-    float f = static_cast<float>(v);
-    if (static_cast<double>(f) > v) f = std::nextafterf(f, -INFINITY);
-    return f;
-}
-static float round_up(double v) {
-    float f = static_cast<float>(v);
-    if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
-    return f;
 }
 
 namespace {
@@ -524,18 +535,10 @@ struct Collapser {
 
 Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin) {
     Bvh4 out;
-    double m = max_abs_origin;
-    auto grow_abs = [&](const double* p) { for (int a = 0; a < 3; ++a) if (std::isfinite(p[a])) m = std::max(m, std::fabs(p[a])); };
     double rl[3], rh[3];
     store(rl, bvh.root_box.lo);
     store(rh, bvh.root_box.hi);
-    grow_abs(rl);
-    grow_abs(rh);
-    // Absolute FP32 errors of the device slab test (device_rt.h: node4_test), in world units, for coordinates bounded
-    // by m: rounding the ray origin (2^-24 m), the product o*inv (2^-24 m), org*inv - o*inv (2^-23 m) -- under
-    // 5 * 2^-24 m in total.  Ray origins are the camera or surface points inside the root box moved by at most ~1e-3
-    // (tracer.h:201, shading.h:68,93).  Relative errors are covered on the device.
-    out.pad = (m + 0.01) * std::ldexp(1.0, -21);
+    out.pad = node4_pad(bvh.root_box, max_abs_origin);
     out.root_ref = bvh.root_ref;
     out.max_depth = 0;
     if (!bvh.nodes.empty() && bvh.root_ref >= 0) {

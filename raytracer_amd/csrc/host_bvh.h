@@ -35,6 +35,10 @@ struct Bvh4 {
     int32_t max_depth = 0;         // 4-wide levels on the longest root->leaf path
 };
 Bvh4 to_node4(const HostBvh& bvh, double max_abs_origin);
+// The absolute outward pad of every box of the device image, and the FP32 roundings used for the root box.
+double node4_pad(const Box& root_box, double max_abs_origin);
+float round_down(double v);
+float round_up(double v);
 
 // What the device traverses: a binned-SAH hierarchy with single-primitive leaves over `boxes` (one per primitive,
 // indexed by the reference's depth-first order, so that leaf references are primitive indices).  At most max_depth

@@ -1,0 +1,98 @@
+"""The hierarchy built ON the GPU (bvh_build.hip: Morton codes, radix sort, binary radix tree,
+bottom-up boxes, 4-wide collapse, 8-bit quantisation) against the same two bars as the host builder's:
+
+* structure -- the node array read back from device memory is a conservative cover of the reference's per-shape boxes
+  (transformed_shape.h:42-77, plane.cpp:11-46) and reaches every primitive exactly once within the traversal stack's
+  depth: the checker of tests/test_bvh_device_image.py, unchanged;
+* frames -- the closest hit does not depend on the hierarchy and ties are decided by the reference's visit order, so
+  the frames must be the bytes the SAH-built scene renders, and within the north-star bar (8-bit max |diff| <= 1) of
+  the reference's golden images."""
+import numpy as np
+import pytest
+
+import helpers
+import raytracer_amd as rt
+from test_bvh_device_image import _check_image, _random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def lbvh(gpu):
+    rt.set_bvh_builder("lbvh")
+    yield
+    rt.set_bvh_builder("default")
+
+
+def _device_image(desc):
+    scene = rt.Scene(desc)
+    img = scene.bvh_nodes()
+    img["prim_boxes"] = rt.bvh_device_image(desc)["prim_boxes"]   # primitive order is the reference's for every builder
+    return scene, img
+
+
+@pytest.mark.parametrize("name", ["bvh_100_normals", "c1_default", "gal_shapes", "gal_bike", "own_complex", "own_motion", "bvh_2_normals"])
+def test_device_built_image_covers_reference_boxes(lbvh, name):
+    if name not in helpers.MANIFEST:
+        pytest.skip("no such golden case")
+    desc, _, _ = helpers.load_case(name)
+    scene, img = _device_image(desc)
+    scene.close()
+    assert img["builder"] == "lbvh" and img["info"].n_prims == desc.desc.n_shapes
+    _check_image(img, desc.desc.n_shapes, check_root_box=False)
+
+
+@pytest.mark.parametrize("n,clustered", [(2, False), (3, False), (5, False), (1000, False), (3000, True), (50_000, False)])
+def test_device_built_image_random_scenes(lbvh, n, clustered):
+    """clustered: five tight clusters 1000 units apart and n/10 coincident centres (equal Morton codes)."""
+    sb = _random_scene(n, 11 + n, clustered)
+    scene, img = _device_image(sb)
+    scene.close()
+    assert img["builder"] == "lbvh"
+    _check_image(img, n, check_root_box=False)
+    leaves = int((img["nodes"]["child"] < 0).sum())
+    assert leaves == n   # single-primitive leaves
+    if n >= 1000:
+        assert img["info"].n_nodes <= 0.5 * n
+
+
+@pytest.mark.parametrize("name", ["bvh_100_shaded", "c1_shadows_fresnel", "gal_shapes", "own_glass_env", "own_complex", "own_motion"])
+def test_frames_do_not_depend_on_the_builder(gpu, name):
+    desc, params, golden = helpers.load_case(name)
+    frames = {}
+    for builder in ("sah", "lbvh"):
+        rt.set_bvh_builder(builder)
+        try:
+            scene = rt.Scene(desc)
+        finally:
+            rt.set_bvh_builder("default")
+        assert scene.bvh_nodes()["builder"] == builder
+        frames[builder] = scene.render(params)
+        scene.close()
+    mx, nd, _ = helpers.diff_stats(frames["lbvh"], golden)
+    assert mx <= 1 and nd <= 0.01 * golden.size
+    # FP64 atomics of the wavefront schedule may reorder a pixel's sum: <= 1 level, rarely
+    mx, nd, _ = helpers.diff_stats(frames["lbvh"], frames["sah"])
+    assert mx <= 1 and nd <= 1e-4 * golden.size
+
+
+def test_large_scene_builds_in_milliseconds_and_renders_the_same_frame(gpu):
+    """200 000 random ellipsoids: device build time, depth, and the frame against the SAH-built scene."""
+    from raytracer_amd import workloads
+    desc = workloads.bvh_stress_scene(200_000, 480, 270)
+    params = workloads.default_config().params(rng="d0")
+    out = {}
+    for builder in ("sah", "lbvh"):
+        rt.set_bvh_builder(builder)
+        try:
+            scene = rt.Scene(desc)
+        finally:
+            rt.set_bvh_builder("default")
+        img = scene.bvh_nodes()
+        assert img["builder"] == builder
+        out[builder] = (scene.render(params), img)
+        scene.close()
+    assert np.array_equal(out["sah"][0], out["lbvh"][0])
+    img = out["lbvh"][1]
+    assert img["info"].max_depth <= 32 and 0.0 < img["device_build_ms"] < 50.0
+    assert int((img["nodes"]["child"] < 0).sum()) == 200_000
