@@ -128,37 +128,51 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
     HostArrays h;
     h.prims.resize(d.n_shapes);
     h.file_order.resize(d.n_shapes);
+    // positions in xforms / quads: a running count over the primitives in order; the records are then filled on host threads
+    std::vector<int32_t> data_index(d.n_shapes);
+    int32_t n_xforms = 0, n_quads = 0;
     for (int k = 0; k < d.n_shapes; ++k) {
-        int fi = bvh.order[k];
-        const RtShape& s = d.shapes[fi];
-        DPrim& p = h.prims[k];
-        p.type = s.type;
-        p.material = s.material;
-        p.file_index = fi;
-        h.file_order[fi] = k;
-        if (s.type == RT_SHAPE_PLANE) {
-            // plane.cpp:49-74
-            DQuad q{};
-            V3 c0(s.corners), c1(s.corners + 3), c2(s.corners + 6), c3(s.corners + 9);
-            V3 e1 = c1 - c0, e2 = c2 - c0;
-            store(q.v0, c0); store(q.e1, e1); store(q.e2, e2);
-            store(q.w0, c1); store(q.f1, c3 - c1); store(q.f2, c2 - c1);
-            store(q.n, normalize(cross(e1, e2)));
-            std::memcpy(q.vel, s.velocity, sizeof(q.vel));
-            p.data = static_cast<int32_t>(h.quads.size());
-            h.quads.push_back(q);
+        const int32_t type = d.shapes[bvh.order[k]].type;
+        if (type == RT_SHAPE_PLANE) {
+            data_index[k] = n_quads++;
             h.features |= RT_FEAT_QUAD;
         } else {
-            DXform x{};
-            std::memcpy(x.inv, s.inv_transform, 12 * sizeof(double));
-            x.inv33 = s.inv_transform[15];
-            std::memcpy(x.vel, s.velocity, sizeof(x.vel));
-            x.disp = s.max_displacement;
-            p.data = static_cast<int32_t>(h.xforms.size());
-            h.xforms.push_back(x);
-            h.features |= (s.type == RT_SHAPE_SPHERE) ? RT_FEAT_SPHERE : (s.type == RT_SHAPE_CUBE) ? RT_FEAT_CUBE : RT_FEAT_COMPLEX;
+            data_index[k] = n_xforms++;
+            h.features |= (type == RT_SHAPE_SPHERE) ? RT_FEAT_SPHERE : (type == RT_SHAPE_CUBE) ? RT_FEAT_CUBE : RT_FEAT_COMPLEX;
         }
     }
+    h.xforms.resize(n_xforms);
+    h.quads.resize(n_quads);
+    parallel_ranges(static_cast<size_t>(d.n_shapes), [&](size_t begin, size_t end) {
+        for (size_t k = begin; k < end; ++k) {
+            int fi = bvh.order[k];
+            const RtShape& s = d.shapes[fi];
+            DPrim& p = h.prims[k];
+            p.type = s.type;
+            p.material = s.material;
+            p.file_index = fi;
+            p.data = data_index[k];
+            h.file_order[fi] = static_cast<int32_t>(k);
+            if (s.type == RT_SHAPE_PLANE) {
+                // plane.cpp:49-74
+                DQuad q{};
+                V3 c0(s.corners), c1(s.corners + 3), c2(s.corners + 6), c3(s.corners + 9);
+                V3 e1 = c1 - c0, e2 = c2 - c0;
+                store(q.v0, c0); store(q.e1, e1); store(q.e2, e2);
+                store(q.w0, c1); store(q.f1, c3 - c1); store(q.f2, c2 - c1);
+                store(q.n, normalize(cross(e1, e2)));
+                std::memcpy(q.vel, s.velocity, sizeof(q.vel));
+                h.quads[p.data] = q;
+            } else {
+                DXform x{};
+                std::memcpy(x.inv, s.inv_transform, 12 * sizeof(double));
+                x.inv33 = s.inv_transform[15];
+                std::memcpy(x.vel, s.velocity, sizeof(x.vel));
+                x.disp = s.max_displacement;
+                h.xforms[p.data] = x;
+            }
+        }
+    });
     h.materials.resize(d.n_materials);
     for (int i = 0; i < d.n_materials; ++i) {
         const RtMaterial& m = d.materials[i];
@@ -235,7 +249,7 @@ static double max_camera_coordinate(const RtSceneDesc& desc) {
 // The hierarchy the device traverses, from the reference-topology tree that fixes the primitive order.
 static HostBvh traversal_tree(const RtSceneDesc& desc, const HostBvh& ref) {
     if (chosen_builder() == RT_BVH_MEDIAN) return ref;   // traverse the reference topology itself (A/B runs)
-    return build_traversal_bvh(shape_boxes(desc, ref.order.data()), kMaxBinaryDepth);
+    return build_traversal_bvh(permuted_boxes(ref.shape_boxes, ref.order), kMaxBinaryDepth);
 }
 static Bvh4 device_image(const RtSceneDesc& desc, const HostBvh& trav) {
     return to_node4(trav, max_camera_coordinate(desc));
@@ -319,7 +333,7 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
         if (!b4.nodes.empty()) std::memcpy(nodes_out, b4.nodes.data(), b4.nodes.size() * sizeof(DNode4));
     }
     if (prim_boxes_out) {
-        const std::vector<Box> boxes = shape_boxes(*desc, ref.order.data());
+        const std::vector<Box> boxes = permuted_boxes(ref.shape_boxes, ref.order);
         for (int k = 0; k < desc->n_shapes; ++k) {
             store(prim_boxes_out + 6 * k, boxes[k].lo);
             store(prim_boxes_out + 6 * k + 3, boxes[k].hi);
@@ -348,7 +362,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     Bvh4 b32;
     sc->builder = chosen_builder();
     if (sc->builder == RT_BVH_LBVH && desc->n_shapes >= 2) {
-        const std::vector<Box> boxes = shape_boxes(*desc, sc->bvh.order.data());
+        const std::vector<Box> boxes = permuted_boxes(sc->bvh.shape_boxes, sc->bvh.order);
         clock.lap("primitive boxes");
         DeviceBvh4 dev4;
         hipError_t herr = hipSuccess;
@@ -384,6 +398,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     }
     sc->depth4 = b32.max_depth;
     sc->node_pad = b32.pad;
+    std::vector<Box>().swap(sc->bvh.shape_boxes);   // 48 bytes per shape the scene no longer needs
     HostArrays h = derive_arrays(*desc, sc->bvh);
     clock.lap("primitive arrays");
 

@@ -564,9 +564,19 @@ std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order) {
     return boxes;
 }
 
+std::vector<Box> permuted_boxes(const std::vector<Box>& boxes, const std::vector<int32_t>& order) {
+    std::vector<Box> out(order.size());
+    parallel_for(order.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) out[i] = boxes[order[i]];
+    });
+    return out;
+}
+
+void parallel_ranges(size_t n, const std::function<void(size_t, size_t)>& body) { parallel_for(n, body); }
+
 HostBvh build_bvh(const RtSceneDesc& desc) {
     const size_t n = static_cast<size_t>(std::max(desc.n_shapes, 0));
-    const std::vector<Box> boxes = shape_boxes(desc, nullptr);
+    std::vector<Box> boxes = shape_boxes(desc, nullptr);
     Builder b{boxes};
     if (n == 0) {
         b.out.root_ref = make_leaf_ref(0, 1);
@@ -584,6 +594,7 @@ HostBvh build_bvh(const RtSceneDesc& desc) {
     b.out.nodes.resize(b.count_nodes(n));
     Builder::Built root = b.build(0, n, 0);
     b.out.order = std::move(b.idx);
+    b.out.shape_boxes = std::move(boxes);   // b.boxes refers to it: not used after this point
     b.out.root_ref = root.ref;
     b.out.root_box = root.box;
     b.out.max_depth = root.depth;

@@ -1,6 +1,7 @@
 // Host BVH construction: the reference's top-down median split (Code/acceleration/bvh.cpp:32-92) over the
 // reference's per-shape world boxes, flattened for the device (device_types.h: DNode).
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
@@ -12,6 +13,7 @@ namespace rt {
 struct HostBvh {
     std::vector<DNode> nodes;      // interior nodes, node 0 = root (empty when the scene has <= 2 shapes)
     std::vector<int32_t> order;    // order[k] = scene-file index of the k-th primitive in depth-first leaf order
+    std::vector<Box> shape_boxes;  // build_bvh: the world box of every shape, in scene-file order (callers may drop it)
     int32_t root_ref = 0;
     Box root_box;
     int32_t max_depth = 0;         // interior-node levels on the longest root->leaf path
@@ -22,6 +24,10 @@ struct HostBvh {
 Box shape_bounds(const RtShape& s, double shutter_time);
 // The boxes of all shapes (host threads); box k belongs to shape order[k], or to shape k when order is NULL.
 std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order);
+// boxes[order[k]] for every k (host threads).
+std::vector<Box> permuted_boxes(const std::vector<Box>& boxes, const std::vector<int32_t>& order);
+// body(begin, end) over disjoint pieces of [0, n) on up to RT_BUILD_THREADS host threads (one piece when n is small).
+void parallel_ranges(size_t n, const std::function<void(size_t, size_t)>& body);
 
 // Device image of the hierarchy: the binary tree collapsed to four children per node with 8-bit quantised child
 // boxes (device_types.h: DNode4).  Every box is first moved outward by an absolute pad that covers the FP32 rounding of
