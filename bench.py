@@ -61,7 +61,7 @@ def parse_args():
                     help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the same frame")
-    ap.add_argument("--cpu-passes", type=int, default=6, help="CPU baseline: frames rendered (sized for ~10 s of CPU work)")
+    ap.add_argument("--cpu-passes", type=int, default=18, help="CPU baseline: frames rendered (sized for ~10 s of CPU work on 16 threads)")
     return ap.parse_args()
 
 
