@@ -580,12 +580,16 @@ __device__ __forceinline__ NodeRegs load_node(const DNode4* n) {
 // The four child boxes of a node against the ray.  Planes are org + q * 2^e on the node's grid, so the slab distance is
 // t = q * (2^e * inv) + (org * inv - o * inv): two per-axis constants per node and one FMA per plane (issued as packed
 // pairs: near and far plane of one axis).  Which plane is the near one follows from the sign of the direction, so the
-// two plane words of an axis are swapped once per node instead of ordering every pair of distances.  Conservative in
-// the same way as box_test32 (absolute errors are in the host pad, host_bvh.cpp: to_node4; relative ones in kSlack;
-// NaNs of axis-parallel rays drop out of min3/max3).  e[c] = entry distance of child c, +inf when missed/unused.
+// two plane words of an axis are swapped once per node instead of ordering every pair of distances.  Conservative like
+// box_test32, but with ALL rounding errors in the host pad (host_bvh.cpp: node4_pad): a relative error eps of a slab
+// distance t = (plane - o) / d is a plane moved by eps * |plane - o| <= eps * 2 * max|coordinate|, so an absolute pad
+// covers it and the node loop carries no slack arithmetic (eight instructions per node less).  NaNs of axis-parallel
+// rays drop out of min3/max3.  e[c] = entry distance of child c, +inf when missed/unused.
 typedef float rt_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, float tmin, float tmax, float e[4]) {
-    constexpr float kSlack = 9.53674316e-7f;  // 2^-20
+#ifdef RT_NODE_SLACK
+    constexpr float kSlack = 9.53674316e-7f;  // 2^-20 (A/B builds: the relative slack the pad replaces)
+#endif
     rt_f2 a[3], b[3];
     unsigned qn[3], qf[3];
 #pragma unroll
@@ -608,8 +612,10 @@ __device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, flo
         }
         float tn = fmaxf(fmaxf(t[0].x, t[1].x), t[2].x);
         float tf = fminf(fminf(t[0].y, t[1].y), t[2].y);
+#ifdef RT_NODE_SLACK
         tn = fmaf(-fabsf(tn), kSlack, tn);
         tf = fmaf(fabsf(tf), kSlack, tf);
+#endif
         tn = fmaxf(tn, tmin);
         tf = fminf(tf, tmax);
         e[c] = (tf >= tn && n.child[c] != kEmptyChild) ? tn : INFINITY;

@@ -360,11 +360,14 @@ double node4_pad(const Box& root_box, double max_abs_origin) {
     auto grow_abs = [&](V3 p) { for (int a = 0; a < 3; ++a) if (std::isfinite(p[a])) m = std::max(m, std::fabs(p[a])); };
     grow_abs(root_box.lo);
     grow_abs(root_box.hi);
-    // Absolute FP32 errors of the device slab test (device_rt.h: node4_test), in world units, for coordinates bounded
-    // by m: rounding the ray origin (2^-24 m), the product o*inv (2^-24 m), org*inv - o*inv (2^-23 m) -- under
-    // 5 * 2^-24 m in total.  Ray origins are the camera or surface points inside the root box moved by at most ~1e-3
-    // (tracer.h:201, shading.h:68,93).  Relative errors are covered on the device.
-    return (m + 0.01) * std::ldexp(1.0, -21);
+    // FP32 errors of the device slab test (device_rt.h: node4_test), as plane displacements in world units, for
+    // coordinates bounded by m.  Absolute ones: rounding the ray origin (2^-24 m), the product o*inv (2^-24 m),
+    // org*inv - o*inv (2^-23 m) -- under 5 * 2^-24 m in total, covered by 2^-21 m.  Relative ones: the reciprocal of
+    // the direction (v_rcp_f32 of the rounded component: 1.5 * 2^-23 + 2^-24) and the final FMA (2^-24) -- under
+    // 1.25 * 2^-22 of the slab distance, i.e. of |plane - o| <= 2 m along the axis: under 1.25 * 2^-21 m, covered by
+    // 2^-19 m (3.2 times over).  Ray origins are the camera or surface points inside the root box moved by at most
+    // ~1e-3 (tracer.h:201, shading.h:68,93), hence the 0.01.
+    return (m + 0.01) * (std::ldexp(1.0, -21) + std::ldexp(1.0, -19));
 }
 float round_down(double v) {
     float f = static_cast<float>(v);
