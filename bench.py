@@ -76,12 +76,44 @@ def cpu_baseline(scene_desc, params, row_step, passes):
         _, cnt = oracle_py.render(scene_desc, params, threads=threads, counters=True, rows=(0, h, row_step))
         secs += oracle_py.last_render_seconds()
         rays += cnt[0]
+    try:
+        check = reference_check(threads)
+    except Exception as e:   # the baseline itself does not depend on it
+        check = {"error": str(e)[:200]}
     return {
         "value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": oracle_py.last_threads(), "kind": "port",
+        "reference_check": check,
         "sample": "same 10^6-sphere 1080p frame, every %d-th row, %d passes (%d rays), pixel loop only (BVH build excluded), %.2f s on %d threads"
                   % (row_step, passes, rays, secs, oracle_py.last_threads()),
         "box_tests_per_ray": round(cnt[1] / cnt[0], 2), "prim_tests_per_ray": round(cnt[2] / cnt[0], 2),
     }
+
+
+def reference_check(threads, n_spheres=100_000):
+    """The REAL reference binary (oracle/_ref/ref_raytracer: the reference's own sources compiled in place by
+    oracle/Makefile, with only its RNG replaced by the deterministic shim) next to the port on an input it loads in
+    seconds: the same C2 frame with 10^5 spheres (at 10^6 its BVH build alone takes 32 s).  Render-only time of the
+    reference = wall time of the 1080p run minus that of a 16x9 run of the same scene (load + build), SURVEY 8(d)."""
+    import oracle_py
+    import run_ref
+    if not os.path.exists(run_ref.REF_BIN):
+        return None
+    text = workloads.bvh_stress_scene_text(n_spheres, 1920, 1080)
+    cfg_text = open(workloads.DEFAULT_CONFIG_PATH).read()
+    t0 = time.perf_counter()
+    run_ref.run_reference(run_ref.override_resolution(text, 16, 9), cfg_text, flags=["--parallel"], rng="d0", threads=threads)
+    t1 = time.perf_counter()
+    ref_img, _ = run_ref.run_reference(text, cfg_text, flags=["--parallel"], rng="d0", threads=threads)
+    t2 = time.perf_counter()
+    ref_secs = max(1e-3, (t2 - t1) - (t1 - t0))
+    cfg = rt.Config(text=cfg_text)
+    scene_file = rt.SceneFile(text=text, texture_root=ROOT, config=cfg)
+    port_img, cnt = oracle_py.render(scene_file, cfg.params(rng="d0"), threads=threads, counters=True)
+    port_secs = oracle_py.last_render_seconds()
+    return {"workload": "C2 with %d spheres, 1920x1080, 1 spp (scene text parsed by both)" % n_spheres, "cores": threads,
+            "reference_mrays_per_s": round(cnt[0] / ref_secs / 1e6, 4), "port_mrays_per_s": round(cnt[0] / port_secs / 1e6, 4),
+            "port_over_reference": round(ref_secs / port_secs, 3), "reference_render_s": round(ref_secs, 3),
+            "images_identical": bool(np.array_equal(ref_img, port_img))}
 
 
 def main():

@@ -40,3 +40,23 @@ def bvh_stress_scene(n_spheres=1_000_000, width=1920, height=1080, seed=12345, s
     light.intensity[:] = [10.0, 10.0, 10.0]
     light.radius = 0.0
     return rt.SceneBuilder(cam, [light], shapes, [rt.default_material()], shutter_time=shutter_time)
+
+
+def bvh_stress_scene_text(n_spheres, width=1920, height=1080, seed=12345):
+    """The same workload as scene-file text in the reference's grammar (scene.cpp:124-546; layout of
+    ASCII/BVH_tests/scene_3.txt), 9 decimals.  For runs of the reference binary next to this library on one input: parse
+    this text with rt.SceneFile so that both sides see the rounded numbers."""
+    rng = np.random.default_rng(seed)
+    n = int(n_spheres)
+    tx, ty, tz = rng.uniform(-0.8, 1.8, n), rng.uniform(-0.8, 1.6, n), rng.uniform(-1.2, 1.05, n)
+    rz = rng.uniform(-np.pi, np.pi, n)
+    r = 0.35 / np.cbrt(n)
+    sc = rng.uniform(0.5 * r, 1.5 * r, (n, 3))
+    head = ("CAMERA\n  location 2.500000 -2.500000 1.500000\n  gaze_direction -0.506798 0.760196 -0.406519\n"
+            "  up_vector -0.225496 0.338244 0.913642\n  focal_length 50.000000\n  sensor_size 36.000000 24.000000\n"
+            "  resolution %d %d\n  f_stop 99999.0\n  focal_distance 10.0\nEND_CAMERA\n\n"
+            "POINT_LIGHT\n  location 0.233330 0.717368 1.959181\n  intensity 10.000000 10.000000 10.000000\n  radius 0.000000\n"
+            "END_POINT_LIGHT\n\n" % (width, height))
+    blocks = ["SPHERE\n  translation %.9f %.9f %.9f\n  rotation_euler_radians 0.000000000 0.000000000 %.9f\n  scale %.9f %.9f %.9f\nEND_SPHERE\n"
+              % (tx[i], ty[i], tz[i], rz[i], sc[i, 0], sc[i, 1], sc[i, 2]) for i in range(n)]
+    return head + "\n".join(blocks)

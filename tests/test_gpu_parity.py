@@ -76,3 +76,30 @@ def test_row_tile_partition_reassembles(gpu):
             frame |= part  # every part writes only its own rows into a zeroed frame
         assert np.array_equal(frame, full), (parts, tile)
     scene.close()
+
+
+def test_full_hd_frame_matches_the_reference_binary(gpu):
+    """A frame of BASELINE's config 2 at a size the REAL reference still loads in seconds (10^5 ellipsoids, 1920x1080,
+    1 spp): oracle/_ref/ref_raytracer (the reference's own sources, compiled in place; it travels with the tree) renders
+    the scene text, the HIP path renders the same text parsed by rt_scene_file_parse, with every hierarchy builder."""
+    import os
+    import run_ref
+    from raytracer_amd import workloads
+    if not os.path.exists(run_ref.REF_BIN):
+        pytest.skip("reference binary not built (make -C oracle ref)")
+    text = workloads.bvh_stress_scene_text(100_000, 1920, 1080)
+    cfg_text = open(workloads.DEFAULT_CONFIG_PATH).read()
+    ref_img, _ = run_ref.run_reference(text, cfg_text, flags=["--parallel"], rng="d0", threads=16)
+    cfg = rt.Config(text=cfg_text)
+    scene_file = rt.SceneFile(text=text, texture_root=".", config=cfg)
+    params = cfg.params(rng="d0")
+    for builder in ("sah", "lbvh"):
+        rt.set_bvh_builder(builder)
+        try:
+            scene = rt.Scene(scene_file)
+        finally:
+            rt.set_bvh_builder("default")
+        img = scene.render(params)
+        scene.close()
+        mx, nd, _ = helpers.diff_stats(img, ref_img)
+        assert mx <= TOL and nd <= MAX_OFF_FRACTION * img.size, (builder, mx, nd)
