@@ -21,6 +21,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>   // rocprim/iterator/texture_cache_iterator.hpp calls memset without including it
 
 #include <rocprim/rocprim.hpp>
@@ -186,7 +187,7 @@ __device__ __forceinline__ int open_slots(const int b, const int* __restrict__ l
 }
 
 // level[b] = 4-wide level (1 = root) of the 4-wide node rooted at binary node b, 0 = b is inside some 4-wide node.
-__global__ void __launch_bounds__(kB) k_lbvh_mark(const int n, const int lvl, const int* __restrict__ left, const int* __restrict__ right,
+__global__ void __launch_bounds__(kB) k_lbvh_mark(const int n, const int lvl, const int max_levels, const int* __restrict__ left, const int* __restrict__ right,
                                                   const double* __restrict__ nbox, int* level, int4* __restrict__ slots,
                                                   unsigned* __restrict__ flags) {
     const int b = blockIdx.x * kB + threadIdx.x;
@@ -199,9 +200,9 @@ __global__ void __launch_bounds__(kB) k_lbvh_mark(const int n, const int lvl, co
     for (int i = 0; i < count; ++i)
         if (refs[i] >= 0) {
             interior = true;
-            if (lvl < kMaxWideLevels) level[refs[i]] = lvl + 1;
+            if (lvl < max_levels) level[refs[i]] = lvl + 1;
         }
-    if (interior && lvl >= kMaxWideLevels) flags[0] = 1u;   // deeper than the traversal stack allows
+    if (interior && lvl >= max_levels) flags[0] = 1u;   // deeper than the traversal stack allows
     flags[2] = (unsigned)lvl;   // every writer of a launch stores the same value
 }
 
@@ -367,8 +368,10 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
                        d_nbox, d_flags);
     const int one = 1;
     LBVH_TRY(hipMemcpyAsync(d_level, &one, sizeof(int), hipMemcpyHostToDevice, stream));   // binary node 0 roots the 4-wide root
-    for (int lvl = 1; lvl <= kMaxWideLevels; ++lvl)
-        hipLaunchKernelGGL(k_lbvh_mark, dim3(gn), dim3(kB), 0, stream, ni, lvl, d_left, d_right, d_nbox, d_level, d_slots, d_flags);
+    int max_levels = kMaxWideLevels;
+    if (const char* env = getenv("RT_LBVH_MAX_LEVELS")) max_levels = std::max(1, std::min(kMaxWideLevels, atoi(env)));   // tests of the fallback
+    for (int lvl = 1; lvl <= max_levels; ++lvl)
+        hipLaunchKernelGGL(k_lbvh_mark, dim3(gn), dim3(kB), 0, stream, ni, lvl, max_levels, d_left, d_right, d_nbox, d_level, d_slots, d_flags);
     hipLaunchKernelGGL(k_lbvh_used, dim3(gn), dim3(kB), 0, stream, ni, d_level, d_used);
     tb = scan_bytes;
     LBVH_TRY(rocprim::exclusive_scan(d_temp, tb, d_used, d_widx, 0, n - 1, rocprim::plus<int>(), stream));

@@ -96,3 +96,21 @@ def test_large_scene_builds_in_milliseconds_and_renders_the_same_frame(gpu):
     img = out["lbvh"][1]
     assert img["info"].max_depth <= 32 and 0.0 < img["device_build_ms"] < 50.0
     assert int((img["nodes"]["child"] < 0).sum()) == 200_000
+
+
+def test_a_tree_deeper_than_the_stack_falls_back_to_the_host_builder(gpu, monkeypatch):
+    """The device builder reports a tree with more 4-wide levels than the traversal stack allows (32; lowered here
+    through RT_LBVH_MAX_LEVELS, since only adversarial scenes of millions of shapes reach 32) and rt_scene_create then
+    uses the host builder, which bounds its depth."""
+    desc, params, golden = helpers.load_case("bvh_100_shaded")
+    monkeypatch.setenv("RT_LBVH_MAX_LEVELS", "2")
+    rt.set_bvh_builder("lbvh")
+    try:
+        scene = rt.Scene(desc)
+    finally:
+        rt.set_bvh_builder("default")
+    img = scene.bvh_nodes()
+    assert img["builder"] == "sah" and img["info"].max_depth > 2
+    mx, nd, _ = helpers.diff_stats(scene.render(params), golden)
+    scene.close()
+    assert mx <= 1
