@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 constexpr unsigned kXcds = 8;
 constexpr unsigned kNextStride = kFetchCounterWords / kXcds;   // counters 128 bytes apart
 constexpr unsigned kNextBase = 32;     // offset of the fetch counters in WavefrontWorkspace::counters
+constexpr unsigned kLevelCountBase = 4;   // two queue-size words of the levels enqueued without a host round trip
 __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
     return q >= kXcds ? n : (unsigned)(((unsigned long long)n * q / kXcds) & ~63ull);
 }
@@ -266,9 +267,19 @@ __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
 // timed variant carries neither the registers nor the instructions for them.
 template <int F, bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_TRAVERSE_WAVES)
-k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, const unsigned n,
-           unsigned* __restrict__ next, unsigned long long* __restrict__ counters) {
+k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, const unsigned n_host,
+           const unsigned* __restrict__ n_device, const unsigned rays_per_block, unsigned* __restrict__ next,
+           unsigned long long* __restrict__ counters) {
     __shared__ unsigned long long stack_mem[kTravLdsEntries + 1][kBlock];   // + 1: the row branch-free pushes discard into
+    // n_device != NULL: the queue was filled by the shading kernel launched before this one and the host has not read
+    // its size (levels enqueued without a round trip); n_host is then the queue's capacity, which a count that
+    // overflowed is cut to.  One lane adds the level's rays to the frame's total.
+    const unsigned n = n_device ? min(*n_device, n_host) : n_host;
+    if (n_device && blockIdx.x == 0 && threadIdx.x == 0 && n != 0u) atomicAdd(&counters[0], (unsigned long long)n);
+    // The host sized the grid by the bound it knows; workgroups beyond what the actual count calls for (the host's own
+    // rule: rays_per_block rays each) leave at once -- thousands of idle waves polling the eight fetch counters would
+    // serialise on them for longer than a small level takes to trace.
+    if (n == 0u || (n_device && blockIdx.x * (unsigned long long)rays_per_block >= n)) return;
     TravStack stack;
     stack.lds = &stack_mem[0][threadIdx.x];
     stack.stride = kBlock;
@@ -631,8 +642,10 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 // inside the wave first and only the first lane of each run issues the three atomics.
 template <int F>
 __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayQ rays,
-                                                  const HitQ hits, const unsigned n, const EmitCtx E,
-                                                  double* __restrict__ accum) {
+                                                  const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
+                                                  const EmitCtx E, double* __restrict__ accum) {
+    const unsigned n = n_device ? min(*n_device, n_host) : n_host;   // see k_traverse; the grid covers n_host
+    if (blockIdx.x * kBlock >= n) return;
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     D3 c = mk(0.0, 0.0, 0.0);
@@ -750,31 +763,85 @@ struct Driver {
         }
         return ws.events[ws.events_used++];
     }
-    template <int F> void launch_traverse(int q, unsigned n) {
+    template <int F> void launch_traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
         const bool timed = ws.events_used + 2 <= kMaxTimedEvents;
         hipEvent_t e0 = timed ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
         if (e1) (void)hipEventRecord(e0, stream);
-        launch_traverse_kernel<F>(q, n);
+        launch_traverse_kernel<F>(q, n, n_device);
         if (e1) (void)hipEventRecord(e1, stream);
         else if (e0) --ws.events_used;   // keep start/stop pairs whole
     }
-    template <int F> void launch_traverse_kernel(int q, unsigned n) {
+    template <int F> void launch_traverse_kernel(int q, unsigned n, const unsigned* n_device) {
         // Persistent grid sized by the work: at least RT_RAYS_PER_LANE rays per lane, so that lanes can be refilled and
         // a small queue (a part of a frame, a deep level of the ray tree) leaves the other CUs to concurrent streams.
         const unsigned per_block = kBlock * (unsigned)std::max(1, ws.rays_per_lane);
         const unsigned want = (n + per_block - 1) / per_block;
         const unsigned blocks = std::max(1u, std::min((unsigned)traverse_blocks, want));
         if (P.count_tests)
-            hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n,
+            hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
                                ws.counters + kNextBase, ws.stats);
         else
-            hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n,
+            hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
                                ws.counters + kNextBase, ws.stats);
     }
-    template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo) {
-        EmitCtx E{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
+    template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr,
+                                       unsigned* count = nullptr) {
+        EmitCtx E{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, count ? count : ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
         hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
-                           E, ws.accum);
+                           n_device, E, ws.accum);
+    }
+    void traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
+        if (variant == 0) launch_traverse<kSpheres>(q, n, n_device);
+        else if (variant == 1) launch_traverse<kAnalytic>(q, n, n_device);
+        else launch_traverse<kFull>(q, n, n_device);
+    }
+    void shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr, unsigned* count = nullptr) {
+        if (variant == 0) launch_shade<kSpheres>(q, start, n, qo, n_device, count);
+        else if (variant == 1) launch_shade<kAnalytic>(q, start, n, qo, n_device, count);
+        else launch_shade<kFull>(q, start, n, qo, n_device, count);
+    }
+
+    // A whole ray tree without a host round trip per level: every level's queue size stays on the device (the kernels
+    // of level L + 1 read the count the shading kernel of level L left), grids are sized by what the host knows -- the
+    // level cannot hold more than the previous level's bound times its fan-out, nor more than a queue -- and the queue
+    // overflow flag, the size of the last queue and the ray total are read back ONCE at the end.  Optimistic: a level
+    // that outgrows its queue (the kernels never write past it) makes the caller render the frame again level by level
+    // with batches (process()).  Returns 0 = done, 1 = overflow; rays still queued after `levels` levels (chains of
+    // shadow segments through transmitting surfaces) are finished by process().
+    int run_levels(int q, unsigned n0, int levels) {
+        unsigned* cnt = ws.counters + kLevelCountBase;   // two words, used alternately
+        if (!ok(hipMemsetAsync(ws.counters + 2, 0, sizeof(unsigned), stream))) { release(q); return 0; }
+        if (!ok(hipMemsetAsync(ws.stats, 0, sizeof(unsigned long long), stream))) { release(q); return 0; }
+        size_t bound = n0;
+        int level = 0;
+        for (; level < levels && err == hipSuccess; ++level) {
+            const unsigned* n_dev = level == 0 ? nullptr : cnt + (level & 1);
+            const unsigned n = (unsigned)bound;
+            if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) break;
+            traverse(q, n, n_dev);
+            const int qo = acquire();
+            if (qo < 0) break;
+            unsigned* out_count = cnt + ((level + 1) & 1);
+            if (!ok(hipMemsetAsync(out_count, 0, sizeof(unsigned), stream))) { release(qo); break; }
+            shade(q, 0, n, qo, n_dev, out_count);
+            release(q);   // stream order: whatever reuses these buffers runs after this level's kernels
+            q = qo;
+            bound = std::min<size_t>(ws.capacity, bound * fanout(level));
+        }
+        unsigned res[2] = {0, 0};
+        unsigned long long total = 0;
+        if (err == hipSuccess) {
+            ok(hipMemcpyAsync(&res[0], cnt + (level & 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            ok(hipMemcpyAsync(&res[1], ws.counters + 2, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            ok(hipMemcpyAsync(&total, ws.stats, sizeof(total), hipMemcpyDeviceToHost, stream));
+            ok(hipStreamSynchronize(stream));
+        }
+        if (err != hipSuccess) { release(q); return 0; }
+        if (res[1]) { release(q); ws.levels_overflowed = true; return 1; }
+        rays_traced += n0 + total;   // level 0 was launched with a host count
+        if (res[0] != 0u) process(q, res[0], level);
+        else release(q);
+        return 0;
     }
 
     // Trace and shade the n rays of queue q (owned by this call, released when fully consumed), then their children.
@@ -782,14 +849,10 @@ struct Driver {
         if (err != hipSuccess || n == 0) { release(q); return; }
         // level 0: k_raygen has zeroed the fetch counters
         if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) { release(q); return; }
-        if (variant == 0) launch_traverse<kSpheres>(q, n);
-        else if (variant == 1) launch_traverse<kAnalytic>(q, n);
-        else launch_traverse<kFull>(q, n);
+        traverse(q, n);
         rays_traced += n;
         if (!may_emit) {   // no material spawns rays and shadows are off: shade and return, nothing to read back (asynchronous)
-            if (variant == 0) launch_shade<kSpheres>(q, 0, n, -1);
-            else if (variant == 1) launch_shade<kAnalytic>(q, 0, n, -1);
-            else launch_shade<kFull>(q, 0, n, -1);
+            shade(q, 0, n, -1);
             release(q);
             return;
         }
@@ -800,9 +863,7 @@ struct Driver {
             const int qo = acquire();
             if (qo < 0) break;
             if (!ok(hipMemsetAsync(ws.counters + 1, 0, 2 * sizeof(unsigned), stream))) { release(qo); break; }
-            if (variant == 0) launch_shade<kSpheres>(q, start, m, qo);
-            else if (variant == 1) launch_shade<kAnalytic>(q, start, m, qo);
-            else launch_shade<kFull>(q, start, m, qo);
+            shade(q, start, m, qo);
             unsigned res[2] = {0, 0};
             if (!ok(hipMemcpyAsync(res, ws.counters + 1, sizeof(res), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
                 release(qo);
@@ -898,15 +959,33 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     int ns = (int)std::min<size_t>((size_t)params.spp, std::max<size_t>(1, max_primary / ((size_t)W * 8)));
     int rows_per_chunk = (int)std::min<size_t>((size_t)params.part_rows, std::max<size_t>(8, (max_primary / ((size_t)W * ns)) / 8 * 8));
     if ((size_t)rows_per_chunk * W * ns > ws.capacity) return hipErrorInvalidValue;  // frame wider than the queue: raise RT_QUEUE_RAYS
+    // A frame that is one chunk is first tried without host round trips between the levels of its ray tree
+    // (Driver::run_levels); RT_SYNC_LEVELS=1 keeps the level-by-level path (A/B runs, tests).
+    const bool one_chunk = rows_per_chunk >= params.part_rows && ns >= params.spp;
+    // (a scene whose ray tree outgrew the queues once on this stream is not tried again)
+    const bool optimistic = may_emit && one_chunk && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
+    // levels of the ray tree: radiance rays of depth max_depth .. 1, the shadow rays of the last of them, and a few
+    // segments of shadow rays that continue through transmitting surfaces (longer chains are finished level by level)
+    const int levels = std::max(1, params.max_depth) + (params.shadows ? 1 : 0) + ((params.shadows && scene.transparent_materials) ? 4 : 0);
     for (int row0 = 0; row0 < params.part_rows && D.err == hipSuccess; row0 += rows_per_chunk) {
         const int rows = std::min(rows_per_chunk, params.part_rows - row0);
         for (int s0 = 0; s0 < params.spp && D.err == hipSuccess; s0 += ns) {
             Chunk ck{row0, rows, s0, std::min(ns, params.spp - s0)};
             const long long n = (long long)rows * W * ck.ns;
-            const int q = D.acquire();
+            int q = D.acquire();
             if (q < 0) break;
             hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
                                ws.counters + kNextBase);
+            if (optimistic) {
+                if (D.run_levels(q, (unsigned)n, levels) == 0) continue;
+                // a level outgrew its queue: start the frame over, level by level with batches
+                if (D.err != hipSuccess) break;
+                if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
+                D.rays_traced = 0;
+                if ((q = D.acquire()) < 0) break;
+                hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
+                                   ws.counters + kNextBase);
+            }
             D.process(q, (unsigned)n, 0);
         }
     }

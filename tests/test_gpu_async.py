@@ -136,3 +136,43 @@ def test_small_queues_with_many_samples(gpu, monkeypatch):
     mx, nd, n1 = helpers.diff_stats(img, ref)
     assert mx <= 1 and nd <= 0.01 * img.size
     assert helpers.psnr(img, hi) >= psnr_ref - 0.5 or helpers.psnr(img, hi) >= helpers.psnr(ref, hi) - 0.1
+
+
+@pytest.mark.parametrize("name", ["c1_shadows_fresnel", "own_glass_env", "bvh_100_shaded"])
+def test_levels_without_round_trips_equal_level_by_level(gpu, name, monkeypatch):
+    """A one-chunk frame enqueues all levels of its ray tree with the queue sizes left on the device
+    (render_wavefront.hip: run_levels); RT_SYNC_LEVELS=1 reads every size back and batches.  Same rays, same frame (FP64
+    atomics may reorder a pixel's sum: <= 1 level)."""
+    desc, params, golden = helpers.load_case(name)
+    out = {}
+    for mode in ("levels", "sync"):
+        if mode == "sync":
+            monkeypatch.setenv("RT_SYNC_LEVELS", "1")
+        scene = rt.Scene(desc)
+        out[mode] = scene.render(params, stats=True)
+        scene.close()
+    (a, sa), (b, sb) = out["levels"], out["sync"]
+    assert int(sa.rays) == int(sb.rays) and sa.rays > 0
+    mx, nd, _ = helpers.diff_stats(a, b)
+    assert mx <= 1 and nd <= 1e-3 * a.size
+    mx, nd, _ = helpers.diff_stats(a, golden)
+    assert mx <= 1
+
+
+def test_a_level_that_outgrows_its_queue_restarts_the_frame_level_by_level(gpu, monkeypatch):
+    """Queue capacity cut to just what the primary rays' children need (RT_QUEUE_RAYS): the glass scene's third level is
+    larger than that, the kernels flag the overflow without writing past the queue, and the frame is rendered again
+    with batches: same ray count and frame as with ample queues."""
+    desc, params, golden = helpers.load_case("own_glass_env")
+    scene = rt.Scene(desc)
+    ref, st_ref = scene.render(params, stats=True)
+    scene.close()
+    fan = 1 + 1 + (2 * desc.desc.n_lights * params.shadow_samples if params.shadows else 0)
+    cap = max(4096, desc.width * desc.height * fan)
+    monkeypatch.setenv("RT_QUEUE_RAYS", str(cap))
+    scene = rt.Scene(desc)
+    img, st = scene.render(params, stats=True)
+    scene.close()
+    assert int(st.rays) == int(st_ref.rays)
+    mx, nd, _ = helpers.diff_stats(img, ref)
+    assert mx <= 1 and nd <= 1e-3 * img.size
