@@ -237,7 +237,7 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
  * equal-distance hits -- always comes from the host pass; the closest hit does not depend on the hierarchy, so all
  * builders yield the same frames.
  *   RT_BVH_SAH     binned surface-area heuristic on host threads (default; fewest node visits per ray)
- *   RT_BVH_LBVH    built on the GPU: Morton order, radix sort, binary radix tree, bottom-up boxes, 4-wide collapse and
+ *   RT_BVH_LBVH    built on the GPU: Morton order, radix sort, binary radix tree, segment-tree boxes, 4-wide collapse and
  *                  8-bit quantisation in HIP kernels.  Milliseconds for 10^6 shapes; falls back
  *                  to RT_BVH_SAH when the tree would be deeper than the traversal stack (32 4-wide levels).
  *   RT_BVH_MEDIAN  the reference's own topology (A/B runs)

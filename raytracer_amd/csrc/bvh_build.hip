@@ -4,7 +4,11 @@
 //   rocprim sort      (code, primitive) pairs
 //   k_lbvh_hierarchy  binary radix tree over the sorted codes, one thread per interior node (Karras 2012; codes are
 //                     made unique by the sorted position, so duplicate centres need no special case)
-//   k_lbvh_fit        boxes bottom-up: the second thread to arrive at a node joins its children's boxes
+//   k_lbvh_leaf_boxes, k_lbvh_seg_level x log2(n), k_lbvh_node_boxes
+//                     boxes of the interior nodes: a node covers a contiguous range of the sorted primitives, so its
+//                     box is a range query on a segment tree over the sorted boxes (built level by level with plain
+//                     loads and stores; no atomics, no fences: a bottom-up walk with one agent-scope fence per step
+//                     took 6.2 ms for 10^6 shapes on this chip, whose eight L2s are only coherent through memory)
 //   k_lbvh_mark x L   collapse to four children per node, one 4-wide level per launch: a node that roots a 4-wide
 //                     node opens, twice, its interior child with the largest surface (host_bvh.cpp: Collapser::open)
 //   rocprim scan      compact numbering of the 4-wide nodes (in binary-node order, i.e. along the Morton curve)
@@ -34,7 +38,7 @@ namespace {
 
 constexpr int kB = 256;
 constexpr int kMaxWideLevels = kTravStackDepth / 3;   // a 4-wide node defers at most three children per level
-constexpr int kMaxWalk = 192;                         // steps of the bottom-up walk: 63 code bits + 31 index bits at most
+constexpr int kMaxSegLevels = 32;
 
 typedef unsigned long long u64;
 
@@ -79,8 +83,8 @@ __device__ __forceinline__ int prefix(const u64* __restrict__ keys, const int n,
 
 // References inside the binary tree: >= 0 interior node, < 0 leaf = ~(sorted position).
 __global__ void __launch_bounds__(kB) k_lbvh_hierarchy(const u64* __restrict__ keys, const int n, int* __restrict__ left,
-                                                       int* __restrict__ right, int* __restrict__ parent_node,
-                                                       int* __restrict__ parent_leaf) {
+                                                       int* __restrict__ right, int* __restrict__ range_lo,
+                                                       int* __restrict__ range_hi) {
     const int i = blockIdx.x * kB + threadIdx.x;
     if (i >= n - 1) return;
     const int d = (prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -101,61 +105,74 @@ __global__ void __launch_bounds__(kB) k_lbvh_hierarchy(const u64* __restrict__ k
     const int lo = min(i, j), hi = max(i, j);
     // gamma in [lo, hi - 1] by construction; clamp so that a wrong step could never index outside the arrays
     const int gm = min(max(gamma, lo), hi - 1);
-    if (gm == lo) { left[i] = ~gm; parent_leaf[gm] = i; }
-    else { left[i] = gm; parent_node[gm] = i; }
-    if (gm + 1 == hi) { right[i] = ~(gm + 1); parent_leaf[gm + 1] = i; }
-    else { right[i] = gm + 1; parent_node[gm + 1] = i; }
-    if (i == 0) parent_node[0] = -1;
+    left[i] = (gm == lo) ? ~gm : gm;
+    right[i] = (gm + 1 == hi) ? ~(gm + 1) : gm + 1;
+    range_lo[i] = lo;   // the sorted primitives this node covers
+    range_hi[i] = hi;
 }
 
-__device__ __forceinline__ double load_coherent(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+// Segment tree over the sorted primitive boxes, one array per level: level 0 = the boxes themselves, entry j of level
+// k = the union of entries 2j and 2j + 1 of level k - 1 (the last entry of an odd level stands alone).
+struct SegLevels {
+    unsigned long long offset[kMaxSegLevels];   // in boxes, from the start of the tree's memory
+    int count[kMaxSegLevels];
+    int levels;
+};
 
-// One thread per leaf walks towards the root.  The first thread to reach a node stops there; the second one finds the
-// box of the other child complete (written before that thread's fence and counter increment), joins both and goes on.
-__global__ void __launch_bounds__(kB) k_lbvh_fit(const double* __restrict__ boxes, const unsigned* __restrict__ vals, const int n,
-                                                 const int* __restrict__ left, const int* __restrict__ right,
-                                                 const int* __restrict__ parent_node, const int* __restrict__ parent_leaf,
-                                                 unsigned* __restrict__ arrived, double* nbox, unsigned* __restrict__ flags) {
+__global__ void __launch_bounds__(kB) k_lbvh_leaf_boxes(const double* __restrict__ boxes, const unsigned* __restrict__ vals, const int n,
+                                                        double* __restrict__ seg, unsigned* __restrict__ flags) {
     const int i = blockIdx.x * kB + threadIdx.x;
     if (i >= n) return;
-    double b[6];
     const unsigned p = vals[i];
     if (p >= (unsigned)n) { flags[1] = 1u; return; }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) b[k] = boxes[6 * (size_t)p + k];
-    int from = ~i;
-    int node = parent_leaf[i];
-    for (int step = 0; step < kMaxWalk; ++step) {
-        if (node < 0 || node >= n - 1) { if (node != -1) flags[1] = 1u; return; }   // -1: the root has been written
-        if (atomicAdd(&arrived[node], 1u) == 0u) return;   // the sibling subtree is not finished: its thread continues
-        __threadfence();
-        const int other = (left[node] == from) ? right[node] : left[node];
-        double o[6];
-        if (other < 0) {
-            const int leaf = ~other;
-            const unsigned q = (leaf < n) ? vals[leaf] : 0u;
-            if (leaf >= n || q >= (unsigned)n) { flags[1] = 1u; return; }
+    for (int k = 0; k < 6; ++k) seg[6 * (size_t)i + k] = boxes[6 * (size_t)p + k];
+}
+
+__global__ void __launch_bounds__(kB) k_lbvh_seg_level(const double* __restrict__ prev, const int prev_count, double* __restrict__ cur,
+                                                       const int cur_count) {
+    const int j = blockIdx.x * kB + threadIdx.x;
+    if (j >= cur_count) return;
+    double b[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = boxes[6 * (size_t)q + k];
-        } else {
-            if (other >= n - 1) { flags[1] = 1u; return; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = load_coherent(&nbox[6 * (size_t)other + k]);
-        }
+    for (int k = 0; k < 6; ++k) b[k] = prev[6 * (size_t)(2 * j) + k];
+    if (2 * j + 1 < prev_count) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            b[k] = fmin(b[k], o[k]);
-            b[3 + k] = fmax(b[3 + k], o[3 + k]);
+            b[k] = fmin(b[k], prev[6 * (size_t)(2 * j + 1) + k]);
+            b[3 + k] = fmax(b[3 + k], prev[6 * (size_t)(2 * j + 1) + 3 + k]);
         }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) nbox[6 * (size_t)node + k] = b[k];
-        __threadfence();   // the box is visible before this thread is counted at the parent
-        from = node;
-        node = parent_node[node];
     }
-    flags[1] = 1u;   // walk longer than any tree over these keys can be deep
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cur[6 * (size_t)j + k] = b[k];
+}
+
+// Box of every interior node = union over its range [lo, hi] of sorted primitives: the usual bottom-up range query, at
+// most two entries per level.  Most nodes cover a handful of primitives and read two or three entries.
+__global__ void __launch_bounds__(kB) k_lbvh_node_boxes(const int n, const int* __restrict__ range_lo, const int* __restrict__ range_hi,
+                                                        const double* __restrict__ seg, const SegLevels L, double* __restrict__ nbox,
+                                                        unsigned* __restrict__ flags) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n - 1) return;
+    int l = range_lo[i], r = range_hi[i] + 1;
+    if (l < 0 || r > n || l >= r) { flags[1] = 1u; return; }
+    double b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    auto add = [&](int level, int j) {
+        const double* e = seg + 6 * (L.offset[level] + (unsigned long long)j);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            b[k] = fmin(b[k], e[k]);
+            b[3 + k] = fmax(b[3 + k], e[3 + k]);
+        }
+    };
+    for (int level = 0; level < L.levels && l < r; ++level) {
+        if (l & 1) add(level, l++);
+        if (r & 1) add(level, --r);
+        l >>= 1;
+        r >>= 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nbox[6 * (size_t)i + k] = b[k];
 }
 
 __device__ __forceinline__ double half_area6(const double* b) {
@@ -314,9 +331,21 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
     const size_t o_keys_in = carve(n * sizeof(u64)), o_keys_out = carve(n * sizeof(u64));
     const size_t o_vals_in = carve(n * sizeof(unsigned)), o_vals_out = carve(n * sizeof(unsigned));
     const size_t o_left = carve(n * sizeof(int)), o_right = carve(n * sizeof(int));
-    const size_t o_pnode = carve(n * sizeof(int)), o_pleaf = carve(n * sizeof(int));
-    const size_t o_zero = off;   // [o_zero, o_zero_end) is cleared: arrival counters, levels, flags
-    const size_t o_arrived = carve(n * sizeof(unsigned)), o_level = carve(n * sizeof(int)), o_flags = carve(4 * sizeof(unsigned));
+    const size_t o_rlo = carve(n * sizeof(int)), o_rhi = carve(n * sizeof(int));
+    SegLevels seg_levels{};
+    size_t seg_boxes = 0;
+    for (int count = ni, k = 0;; ++k) {
+        if (k >= kMaxSegLevels) { *err = hipErrorInvalidValue; return LbvhStatus::device_error; }
+        seg_levels.offset[k] = seg_boxes;
+        seg_levels.count[k] = count;
+        seg_levels.levels = k + 1;
+        seg_boxes += static_cast<size_t>(count);
+        if (count == 1) break;
+        count = (count + 1) / 2;
+    }
+    const size_t o_seg = carve(seg_boxes * 6 * sizeof(double));
+    const size_t o_zero = off;   // [o_zero, o_zero_end) is cleared: levels, flags
+    const size_t o_level = carve(n * sizeof(int)), o_flags = carve(4 * sizeof(unsigned));
     const size_t o_zero_end = off;
     const size_t o_used = carve(n * sizeof(int)), o_widx = carve(n * sizeof(int));
     const size_t o_slots = carve(n * sizeof(int4));
@@ -343,9 +372,9 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
     unsigned* vals_out = reinterpret_cast<unsigned*>(base + o_vals_out);
     int* d_left = reinterpret_cast<int*>(base + o_left);
     int* d_right = reinterpret_cast<int*>(base + o_right);
-    int* d_pnode = reinterpret_cast<int*>(base + o_pnode);
-    int* d_pleaf = reinterpret_cast<int*>(base + o_pleaf);
-    unsigned* d_arrived = reinterpret_cast<unsigned*>(base + o_arrived);
+    int* d_rlo = reinterpret_cast<int*>(base + o_rlo);
+    int* d_rhi = reinterpret_cast<int*>(base + o_rhi);
+    double* d_seg = reinterpret_cast<double*>(base + o_seg);
     int* d_level = reinterpret_cast<int*>(base + o_level);
     unsigned* d_flags = reinterpret_cast<unsigned*>(base + o_flags);   // [0] too deep, [1] inconsistency, [2] deepest 4-wide level
     int* d_used = reinterpret_cast<int*>(base + o_used);
@@ -363,9 +392,12 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
     hipLaunchKernelGGL(k_lbvh_codes, dim3(gl), dim3(kB), 0, stream, d_boxes, ni, grid, keys_in, vals_in);
     size_t tb = sort_bytes;
     LBVH_TRY(rocprim::radix_sort_pairs(d_temp, tb, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream));
-    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(gn), dim3(kB), 0, stream, keys_out, ni, d_left, d_right, d_pnode, d_pleaf);
-    hipLaunchKernelGGL(k_lbvh_fit, dim3(gl), dim3(kB), 0, stream, d_boxes, vals_out, ni, d_left, d_right, d_pnode, d_pleaf, d_arrived,
-                       d_nbox, d_flags);
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(gn), dim3(kB), 0, stream, keys_out, ni, d_left, d_right, d_rlo, d_rhi);
+    hipLaunchKernelGGL(k_lbvh_leaf_boxes, dim3(gl), dim3(kB), 0, stream, d_boxes, vals_out, ni, d_seg, d_flags);
+    for (int k = 1; k < seg_levels.levels; ++k)
+        hipLaunchKernelGGL(k_lbvh_seg_level, dim3((unsigned)((seg_levels.count[k] + kB - 1) / kB)), dim3(kB), 0, stream,
+                           d_seg + 6 * seg_levels.offset[k - 1], seg_levels.count[k - 1], d_seg + 6 * seg_levels.offset[k], seg_levels.count[k]);
+    hipLaunchKernelGGL(k_lbvh_node_boxes, dim3(gn), dim3(kB), 0, stream, ni, d_rlo, d_rhi, d_seg, seg_levels, d_nbox, d_flags);
     const int one = 1;
     LBVH_TRY(hipMemcpyAsync(d_level, &one, sizeof(int), hipMemcpyHostToDevice, stream));   // binary node 0 roots the 4-wide root
     int max_levels = kMaxWideLevels;
