@@ -454,7 +454,9 @@ __device__ __forceinline__ void deposit(const EmitCtx& E, const DParams& P, doub
 }
 
 // Shades one traced ray: returns whether it contributes `contrib` to its pixel, and queues its child rays.
-template <int F>
+// EMIT = false: the frame cannot queue a ray (no material reflects or transmits and shadows are off, or --normals):
+// none of the code that does is compiled in, which halves the registers of the kernel that shades such frames.
+template <int F, bool EMIT>
 __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, const RayRec& q, const HitRec& hr, const EmitCtx& E,
                                           D3& contrib) {
     const Ray r{ld3(q.o), ld3(q.d), q.time};
@@ -462,7 +464,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     Rng rng{q.rng, P.rng_mode == RT_RNG_D0};
     const Cand c{hr.t, hr.prim, hr.tri, hr.bu, hr.bv};
 
-    if (q.kind == kKindShadow) {  // shading.h:42-75, one segment of the transmission chain
+    if (EMIT && q.kind == kKindShadow) {  // shading.h:42-75, one segment of the transmission chain
         if (c.prim < 0) {  // reached the light sample: this sample's share of the light term
             contrib = w;
             return true;
@@ -564,7 +566,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         D3 Hv = normalize(Ld + V);
         double hdn = smax(0.0, dot(Hv, N));
         D3 sp = cmul(ld3(M.specular), I) * exp(M.shininess * log(hdn));        // shading.h:206, fast_pow :177
-        if (!P.shadows) {  // visibility (1,1,1), shading.h:80
+        if (!EMIT || !P.shadows) {  // visibility (1,1,1), shading.h:80
             ad = ad + cmul(diff, mk(1.0, 1.0, 1.0));
             spec = spec + cmul(sp, mk(1.0, 1.0, 1.0));
         } else {
@@ -592,6 +594,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     contrib = cmul(w, ad * ad_weight + spec);
 
     // ---- secondary rays
+    if (!EMIT) return true;
     const int child_depth = q.depth - 1;
     if (child_depth <= 0) return true;  // children would return black without tracing (tracer.h:149)
     if (has_refl) {  // tracer.h:176-219
@@ -640,8 +643,11 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 // memory side at a fraction of the store rate (MI355X_MICROARCH.md, global float atomics), so lanes that follow each
 // other with the same pixel -- the samples of one pixel and their children stay neighbours in the queues -- are summed
 // inside the wave first and only the first lane of each run issues the three atomics.
-template <int F>
-__global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams P, const RayQ rays,
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 1          // waves per SIMD asked of the register allocator for the shading kernel
+#endif
+template <int F, bool EMIT>
+__global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S, const DParams P, const RayQ rays,
                                                   const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
                                                   const EmitCtx E, double* __restrict__ accum) {
     const unsigned n = n_device ? min(*n_device, n_host) : n_host;   // see k_traverse; the grid covers n_host
@@ -654,7 +660,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const DScene S, const DParams 
         const RayRec q = ray_load(rays, i);
         const HitRec hr = hit_load(hits, i);
         D3 contrib = mk(0.0, 0.0, 0.0);
-        if (shade_ray<F>(S, P, q, hr, E, contrib)) {
+        if (shade_ray<F, EMIT>(S, P, q, hr, E, contrib)) {
             c = contrib;
             pixel = q.pixel;
         }
@@ -787,8 +793,12 @@ struct Driver {
     template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr,
                                        unsigned* count = nullptr) {
         EmitCtx E{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, count ? count : ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
-        hipLaunchKernelGGL(k_shade<F>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
-                           n_device, E, ws.accum);
+        if (may_emit)
+            hipLaunchKernelGGL((k_shade<F, true>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
+                               n_device, E, ws.accum);
+        else
+            hipLaunchKernelGGL((k_shade<F, false>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
+                               n_device, E, ws.accum);
     }
     void traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
         if (variant == 0) launch_traverse<kSpheres>(q, n, n_device);

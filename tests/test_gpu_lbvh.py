@@ -1,5 +1,5 @@
 """The hierarchy built ON the GPU (bvh_build.hip: Morton codes, radix sort, binary radix tree,
-bottom-up boxes, 4-wide collapse, 8-bit quantisation) against the same two bars as the host builder's:
+segment-tree boxes, 4-wide collapse, 8-bit quantisation) against the same two bars as the host builder's:
 
 * structure -- the node array read back from device memory is a conservative cover of the reference's per-shape boxes
   (transformed_shape.h:42-77, plane.cpp:11-46) and reaches every primitive exactly once within the traversal stack's
