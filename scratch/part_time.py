@@ -14,7 +14,7 @@ f_list = [int(a) for a in os.environ.get("FLIGHT", "1,2,4,8").split(",")]
 streams = [torch.cuda.Stream(dev) for _ in range(max(f_list))]
 bufs = [torch.empty(1080 * 1920 * 3, dtype=torch.uint8, device=dev) for _ in streams]
 for parts in parts_list:
-    p = cfg.params(rng="d0"); p.tile_rows, p.part_index, p.part_count = 8, 0, parts
+    p = cfg.params(rng="d0"); p.tile_rows, p.part_index, p.part_count = int(os.environ.get("TILE", "8")), int(os.environ.get("PART", "0")), parts
     for F in f_list:
         def run(K):
             for i in range(K):
