@@ -220,15 +220,16 @@ def main():
         value = rays_frame * args.steps / elapsed / 1e6
         alg_bytes = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES + rays_rank * RAY_STATE_BYTES
         achieved = alg_bytes / (traverse_ms * 1e-3) / 1e9 if traverse_ms > 0 else 0.0
-        traffic = None
+        traffic, valu = None, None   # from the committed rocprofv3 --pmc passes of this workload (profiles/): not measurable in-process
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
                 if t.get("spheres") == args.spheres and t.get("n_gpus", 1) == world:
                     traffic = t.get("bytes_per_launch")
+                    valu = t.get("valu")
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         out = {
             "metric": "Mrays/s (primary+secondary) & ms/frame, 1080p Whitted, 1/2/4/8 GPUs", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -246,7 +247,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches_alone,
                          "kernel_ms_in_flight": round(traverse_ms_in_flight, 4), "kernel_launches_in_flight": launches,
-                         "frame_latency_ms": round(render_ms, 4),
+                         "frame_latency_ms": round(render_ms, 4), "valu": valu,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_ray": "64*node_fetches + 160*sphere_tests + 16"},
         }
