@@ -248,11 +248,25 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
 #define RT_BVH_LBVH     1
 #define RT_BVH_MEDIAN   2
 int rt_set_bvh_builder(int builder);
-/* The node array of a device scene copied back to the host (layout: rt_bvh_device_image), for tests of the device
- * builder.  nodes_out: room for max_nodes nodes or NULL; the other outputs may be NULL: root reference, outward pad,
- * the builder that actually built the hierarchy (RT_BVH_*) and, for RT_BVH_LBVH, the device time of the build in ms. */
-int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, int32_t* root_ref_out, double* pad_out,
-                       int32_t* builder_out, double* device_build_ms_out);
+/* How a device scene was built, and its node array copied back to the host (layout: rt_bvh_device_image), for tests
+ * of the device builders.  nodes_out: room for max_nodes nodes or NULL; info_out may be NULL. */
+typedef struct RtBuildInfo {
+    int32_t root_ref;         /* node 0 or a leaf reference */
+    int32_t builder;          /* RT_BVH_*: the builder that actually built the traversal hierarchy */
+    int32_t order_on_device;  /* 1: the reference's visit order was computed on the GPU, 0: on host threads */
+    int32_t reserved;
+    double pad;               /* outward pad of the node boxes */
+    double device_build_ms;   /* RT_BVH_LBVH: device time of the hierarchy build */
+    double device_order_ms;   /* order_on_device: device time of the order pass */
+} RtBuildInfo;
+int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, RtBuildInfo* info_out);
+/* The reference's depth-first visit order of the shapes (what rt_bvh_build_host returns) computed on the GPU: level by
+ * level, every span of the reference's top-down median split (bvh.cpp:32-92) is sorted by the box centre on the span's
+ * axis and halved.  Returns RT_OK and fills order_out (n_shapes ints), or RT_ERR_LIMIT when equal centres meet at a
+ * split -- the reference's result then depends on the internals of its std::nth_element, and the caller uses the host
+ * pass (rt_scene_create does so by itself).  It is used for scenes of at least 65536 shapes unless RT_ORDER_ON_HOST is
+ * set.  device_ms_out may be NULL. */
+int rt_bvh_order_device(const RtSceneDesc* desc, int32_t* order_out, double* device_ms_out);
 
 /* ---- render ------------------------------------------------------------------------------------ */
 

@@ -95,6 +95,11 @@ class RtStats(C.Structure):
                 ("nodes_fetched", C.c_uint64)]
 
 
+class RtBuildInfo(C.Structure):
+    _fields_ = [("root_ref", C.c_int32), ("builder", C.c_int32), ("order_on_device", C.c_int32), ("reserved", C.c_int32),
+                ("pad", C.c_double), ("device_build_ms", C.c_double), ("device_order_ms", C.c_double)]
+
+
 class RtBvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_prims", C.c_int32), ("max_depth", C.c_int32), ("node_bytes", C.c_int32),
                 ("root_min", C.c_double * 3), ("root_max", C.c_double * 3)]
@@ -113,7 +118,7 @@ ABI_SYMBOLS = [
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
     "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
-    "rt_set_bvh_builder", "rt_scene_bvh_nodes",
+    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device",
 ]
 
 
@@ -157,8 +162,8 @@ def _load():
         "rt_bvh_device_image": (i32, [C.POINTER(RtSceneDesc), vp, C.c_int32, C.POINTER(RtBvhInfo), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_double), vp]),
         "rt_set_bvh_builder": (i32, [i32]),
-        "rt_scene_bvh_nodes": (i32, [vp, vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32),
-                               C.POINTER(C.c_double)]),
+        "rt_scene_bvh_nodes": (i32, [vp, vp, C.c_int32, C.POINTER(RtBuildInfo)]),
+        "rt_bvh_order_device": (i32, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
         "rt_part_rows": (i32, [i32, i32, i32, i32]),
@@ -381,6 +386,16 @@ def bvh_build_host(scene_desc):
     return info, order[: d.contents.n_shapes]
 
 
+def bvh_order_device(scene_desc):
+    """The reference's depth-first visit order computed on the GPU: (order, device ms).  Raises RtError(RT_ERR_LIMIT) when
+    equal box centres meet at a split (the host pass then decides, see rt_bvh_order_device)."""
+    d = scene_desc.desc_ptr()
+    order = np.zeros(max(1, d.contents.n_shapes), dtype=np.int32)
+    ms = C.c_double(0.0)
+    _check(lib.rt_bvh_order_device(d, order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)))
+    return order[: d.contents.n_shapes], ms.value
+
+
 NODE4_DTYPE = np.dtype([("org", "<f4", 3), ("exps", "<u4"), ("qlo", "<u4", 3), ("qhi", "<u4", 3), ("child", "<i4", 4),
                         ("pad", "<i4", 2)])   # device_types.h: DNode4 (64 bytes)
 EMPTY_CHILD = 0x7FFFFFFF
@@ -424,14 +439,14 @@ class Scene:
 
     def bvh_nodes(self):
         """The hierarchy as it lies in device memory: dict with `nodes` (NODE4_DTYPE), `root_ref`, `pad`, `builder` (name of
-        the builder that actually built it) and `device_build_ms` (lbvh only)."""
+        the builder that actually built it), `device_build_ms` (lbvh only), `order_on_device` and `device_order_ms`."""
         info = self.bvh_info()
         nodes = np.zeros(max(1, info.n_nodes), dtype=NODE4_DTYPE)
-        root, pad, builder, ms = C.c_int32(0), C.c_double(0.0), C.c_int32(0), C.c_double(0.0)
-        _check(lib.rt_scene_bvh_nodes(self._h, nodes.ctypes.data, len(nodes), C.byref(root), C.byref(pad), C.byref(builder), C.byref(ms)))
+        b = RtBuildInfo()
+        _check(lib.rt_scene_bvh_nodes(self._h, nodes.ctypes.data, len(nodes), C.byref(b)))
         names = {v: k for k, v in BVH_BUILDERS.items()}
-        return {"nodes": nodes[: info.n_nodes], "info": info, "root_ref": root.value, "pad": pad.value, "builder": names[builder.value],
-                "device_build_ms": ms.value}
+        return {"nodes": nodes[: info.n_nodes], "info": info, "root_ref": b.root_ref, "pad": b.pad, "builder": names[b.builder],
+                "device_build_ms": b.device_build_ms, "order_on_device": bool(b.order_on_device), "device_order_ms": b.device_order_ms}
 
     def render(self, params, stats=False):
         """One frame -> uint8 [H, W, 3] (the bytes Image::write would store).  stats=True also returns RtStats."""

@@ -69,6 +69,8 @@ struct rt_scene_s {
     int builder = RT_BVH_SAH;         // what built the device image (RT_BVH_*)
     double node_pad = 0;              // outward pad of its boxes
     double build_ms = 0;              // RT_BVH_LBVH: device time of the build
+    bool order_on_device = false;     // the primitive order came from bvh_order.hip
+    double order_ms = 0;
     int width = 0, height = 0;
     DScene d{};                       // device view (pointers are device pointers)
     std::vector<void*> allocations;   // everything to hipFree
@@ -232,6 +234,7 @@ struct BuildClock {
 };
 
 // Builder of the hierarchy the device traverses: rt_set_bvh_builder(), else RT_BVH_BUILDER = sah | lbvh | median, else SAH.
+constexpr int kDeviceOrderMinShapes = 65536;   // below this the host pass takes a few milliseconds
 static int g_builder = -1;
 static int chosen_builder() {
     if (g_builder >= 0) return g_builder;
@@ -355,8 +358,28 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     sc->width = desc->camera.resolution_x;
     sc->height = desc->camera.resolution_y;
     BuildClock clock;
-    sc->bvh = build_bvh(*desc);
-    clock.lap("reference-order tree");
+    // The primitive order (the reference's visit order): for large scenes on the GPU (bvh_order.hip) unless equal box
+    // centres meet at a split, else -- and always for the reference's own topology -- by the host pass.
+    if (desc->n_shapes >= kDeviceOrderMinShapes && chosen_builder() != RT_BVH_MEDIAN && std::getenv("RT_ORDER_ON_HOST") == nullptr) {
+        std::vector<Box> boxes = shape_boxes(*desc, nullptr);
+        clock.lap("shape boxes");
+        float ms = 0.f;
+        hipError_t herr = hipSuccess;
+        const OrderStatus st = reference_order_device(boxes, g_dev.stream, &sc->bvh.order, &ms, &herr);
+        clock.lap("device order pass (with upload)");
+        if (st == OrderStatus::device_error) return fail(RT_ERR_DEVICE, std::string("device order pass: ") + hipGetErrorString(herr));
+        if (st == OrderStatus::ok) {
+            sc->order_on_device = true;
+            sc->order_ms = ms;
+            sc->bvh.root_box = union_of(boxes);
+            sc->bvh.shape_boxes = std::move(boxes);
+            sc->bvh.root_ref = 0;
+        }
+    }
+    if (!sc->order_on_device) {
+        sc->bvh = build_bvh(*desc);
+        clock.lap("reference-order tree");
+    }
     // The hierarchy the device traverses: built on the GPU (RT_BVH_LBVH) or on host threads.
     DNode4* d_nodes = nullptr;
     Bvh4 b32;
@@ -477,13 +500,17 @@ int rt_set_bvh_builder(int builder) {
     return RT_OK;
 }
 
-int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, int32_t* root_ref_out, double* pad_out, int32_t* builder_out,
-                       double* device_build_ms_out) {
+int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, RtBuildInfo* info_out) {
     if (!scene) return fail(RT_ERR_INVALID, "NULL argument");
-    if (root_ref_out) *root_ref_out = scene->d.root_ref;
-    if (pad_out) *pad_out = scene->node_pad;
-    if (builder_out) *builder_out = scene->builder;
-    if (device_build_ms_out) *device_build_ms_out = scene->build_ms;
+    if (info_out) {
+        info_out->root_ref = scene->d.root_ref;
+        info_out->builder = scene->builder;
+        info_out->order_on_device = scene->order_on_device ? 1 : 0;
+        info_out->reserved = 0;
+        info_out->pad = scene->node_pad;
+        info_out->device_build_ms = scene->build_ms;
+        info_out->device_order_ms = scene->order_ms;
+    }
     if (nodes_out) {
         if (max_nodes < scene->n_nodes4) return fail(RT_ERR_LIMIT, "nodes_out is too small");
         if (scene->n_nodes4 > 0) {
@@ -491,6 +518,28 @@ int rt_scene_bvh_nodes(rt_scene_t scene, void* nodes_out, int32_t max_nodes, int
             HIP_TRY(hipMemcpy(nodes_out, scene->d.nodes, static_cast<size_t>(scene->n_nodes4) * sizeof(DNode4), hipMemcpyDeviceToHost));
         }
     }
+    return RT_OK;
+}
+
+int rt_bvh_order_device(const RtSceneDesc* desc, int32_t* order_out, double* device_ms_out) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (!order_out) return fail(RT_ERR_INVALID, "order_out is NULL");
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    HIP_TRY(hipSetDevice(g_dev.device));
+    if (desc->n_shapes < 2) {
+        if (desc->n_shapes == 1) order_out[0] = 0;
+        if (device_ms_out) *device_ms_out = 0.0;
+        return RT_OK;
+    }
+    std::vector<int32_t> order;
+    float ms = 0.f;
+    hipError_t herr = hipSuccess;
+    const OrderStatus st = reference_order_device(shape_boxes(*desc, nullptr), g_dev.stream, &order, &ms, &herr);
+    if (st == OrderStatus::device_error) return fail(RT_ERR_DEVICE, std::string("device order pass: ") + hipGetErrorString(herr));
+    if (st == OrderStatus::ties) return fail(RT_ERR_LIMIT, "equal box centres meet at a split: the reference's order is decided by its nth_element (use the host pass)");
+    std::memcpy(order_out, order.data(), order.size() * sizeof(int32_t));
+    if (device_ms_out) *device_ms_out = ms;
     return RT_OK;
 }
 

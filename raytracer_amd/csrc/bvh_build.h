@@ -33,4 +33,14 @@ enum class LbvhStatus {
 LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box, double max_abs_origin, hipStream_t stream,
                              DeviceBvh4* out, hipError_t* err);
 
+// The reference's depth-first visit order of the shapes (bvh.cpp:32-92), computed on the device from the shapes' world
+// boxes in scene-file order (bvh_order.hip).  order[k] = scene-file index of the k-th primitive.
+enum class OrderStatus {
+    ok,
+    ties,           // equal box centres meet at a split: the reference's result depends on its nth_element; use the host pass
+    device_error
+};
+OrderStatus reference_order_device(const std::vector<Box>& shape_boxes, hipStream_t stream, std::vector<int32_t>* order, float* device_ms,
+                                   hipError_t* err);
+
 }  // namespace rt

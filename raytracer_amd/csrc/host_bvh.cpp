@@ -577,6 +577,19 @@ std::vector<Box> permuted_boxes(const std::vector<Box>& boxes, const std::vector
 
 void parallel_ranges(size_t n, const std::function<void(size_t, size_t)>& body) { parallel_for(n, body); }
 
+Box union_of(const std::vector<Box>& boxes) {
+    const double inf = std::numeric_limits<double>::infinity();
+    Box all{{inf, inf, inf}, {-inf, -inf, -inf}};
+    std::mutex m;
+    parallel_for(boxes.size(), [&](size_t b, size_t e) {
+        Box part{{inf, inf, inf}, {-inf, -inf, -inf}};
+        for (size_t i = b; i < e; ++i) part = combine(part, boxes[i]);
+        std::lock_guard<std::mutex> g(m);
+        all = combine(all, part);
+    });
+    return all;
+}
+
 HostBvh build_bvh(const RtSceneDesc& desc) {
     const size_t n = static_cast<size_t>(std::max(desc.n_shapes, 0));
     std::vector<Box> boxes = shape_boxes(desc, nullptr);

@@ -24,6 +24,8 @@ struct HostBvh {
 Box shape_bounds(const RtShape& s, double shutter_time);
 // The boxes of all shapes (host threads); box k belongs to shape order[k], or to shape k when order is NULL.
 std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order);
+// The union of all boxes (host threads); an empty list yields an inverted box.
+Box union_of(const std::vector<Box>& boxes);
 // boxes[order[k]] for every k (host threads).
 std::vector<Box> permuted_boxes(const std::vector<Box>& boxes, const std::vector<int32_t>& order);
 // body(begin, end) over disjoint pieces of [0, n) on up to RT_BUILD_THREADS host threads (one piece when n is small).

@@ -114,3 +114,37 @@ def test_a_tree_deeper_than_the_stack_falls_back_to_the_host_builder(gpu, monkey
     mx, nd, _ = helpers.diff_stats(scene.render(params), golden)
     scene.close()
     assert mx <= 1
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 7, 64, 1000, 70_001, 300_000])
+def test_device_order_equals_the_host_order(gpu, n):
+    """bvh_order.hip against host_bvh.cpp: build_bvh, which restates the reference's top-down median split
+    (bvh.cpp:32-92): the same permutation of the shapes, element for element."""
+    sb = _random_scene(n, 100 + n, False)
+    _, host = rt.bvh_build_host(sb)
+    dev, ms = rt.bvh_order_device(sb)
+    assert np.array_equal(host, dev)
+
+
+def test_device_order_reports_ties(gpu):
+    """Equal box centres at a split: the reference's result depends on its std::nth_element, so the device pass refuses
+    (RT_ERR_LIMIT) and rt_scene_create uses the host pass."""
+    sb = _random_scene(3000, 3011, True)   # 300 coincident centres
+    with pytest.raises(rt.RtError) as e:
+        rt.bvh_order_device(sb)
+    assert e.value.code == rt.RT_ERR_LIMIT
+
+
+def test_large_scenes_take_their_order_from_the_device(gpu, monkeypatch):
+    from raytracer_amd import workloads
+    desc = workloads.bvh_stress_scene(100_000, 320, 180)
+    params = workloads.default_config().params(rng="d0")
+    scene = rt.Scene(desc)
+    a, info_a = scene.render(params), scene.bvh_nodes()
+    scene.close()
+    monkeypatch.setenv("RT_ORDER_ON_HOST", "1")
+    scene = rt.Scene(desc)
+    b, info_b = scene.render(params), scene.bvh_nodes()
+    scene.close()
+    assert info_a["order_on_device"] and info_a["device_order_ms"] > 0 and not info_b["order_on_device"]
+    assert np.array_equal(a, b) and np.array_equal(info_a["nodes"], info_b["nodes"])
