@@ -201,8 +201,8 @@ const char* rt_last_error(void);
 
 /* Build the device scene: camera basis (camera.cpp:74-86), per-shape inverse transforms, quads as two
  * triangles (plane.cpp:49-74), world AABBs (transformed_shape.h:42-77, plane.cpp:11-46, complex_*::getBoundingBox),
- * the median-split BVH (bvh.cpp:32-92) flattened to 64-byte nodes, materials, textures, environment; upload all
- * of it to HBM.  Replaces `Scene::Scene` step scene.cpp:102-121 + the object graph the hot loop walks. */
+ * the reference's visit order of the shapes (bvh.cpp:32-92; on the GPU for large scenes), the hierarchy the device
+ * traverses as 64-byte 4-wide nodes (rt_set_bvh_builder), materials, textures, environment; upload all of it to HBM.  Replaces `Scene::Scene` step scene.cpp:102-121 + the object graph the hot loop walks. */
 int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out);
 void rt_scene_destroy(rt_scene_t scene);
 

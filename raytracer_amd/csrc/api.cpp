@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
@@ -50,8 +51,19 @@ struct DeviceState {
 };
 DeviceState g_dev;
 
+// std::vector without the zero fill of resize(): the big per-primitive arrays are written in full right after.
 template <typename T>
-int upload(const std::vector<T>& v, T** out) {
+struct NoInit : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInit<U>; };
+    NoInit() = default;
+    template <typename U> NoInit(const NoInit<U>&) {}
+    template <typename U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using RawVector = std::vector<T, NoInit<T>>;
+
+template <typename T, typename A>
+int upload(const std::vector<T, A>& v, T** out) {
     *out = nullptr;
     if (v.empty()) return RT_OK;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(out), v.size() * sizeof(T)));
@@ -114,10 +126,10 @@ static int validate_desc(const RtSceneDesc* d) {
 
 // Host-side derivation of the device arrays from the description + hierarchy.
 struct HostArrays {
-    std::vector<DPrim> prims;
-    std::vector<int32_t> file_order;
-    std::vector<DXform> xforms;
-    std::vector<DQuad> quads;
+    RawVector<DPrim> prims;
+    RawVector<int32_t> file_order;
+    RawVector<DXform> xforms;
+    RawVector<DQuad> quads;
     std::vector<DMaterial> materials;
     std::vector<DLight> lights;
     int32_t features = 0;
@@ -131,16 +143,22 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
     h.prims.resize(d.n_shapes);
     h.file_order.resize(d.n_shapes);
     // positions in xforms / quads: a running count over the primitives in order; the records are then filled on host threads
-    std::vector<int32_t> data_index(d.n_shapes);
+    RawVector<int32_t> data_index(d.n_shapes);
     int32_t n_xforms = 0, n_quads = 0;
-    for (int k = 0; k < d.n_shapes; ++k) {
-        const int32_t type = d.shapes[bvh.order[k]].type;
-        if (type == RT_SHAPE_PLANE) {
-            data_index[k] = n_quads++;
-            h.features |= RT_FEAT_QUAD;
-        } else {
-            data_index[k] = n_xforms++;
-            h.features |= (type == RT_SHAPE_SPHERE) ? RT_FEAT_SPHERE : (type == RT_SHAPE_CUBE) ? RT_FEAT_CUBE : RT_FEAT_COMPLEX;
+    {
+        RawVector<int32_t> types(d.n_shapes);   // gathered on threads (the shape records are 400 bytes apart), counted in order
+        parallel_ranges(static_cast<size_t>(d.n_shapes), [&](size_t begin, size_t end) {
+            for (size_t k = begin; k < end; ++k) types[k] = d.shapes[bvh.order[k]].type;
+        });
+        for (int k = 0; k < d.n_shapes; ++k) {
+            const int32_t type = types[k];
+            if (type == RT_SHAPE_PLANE) {
+                data_index[k] = n_quads++;
+                h.features |= RT_FEAT_QUAD;
+            } else {
+                data_index[k] = n_xforms++;
+                h.features |= (type == RT_SHAPE_SPHERE) ? RT_FEAT_SPHERE : (type == RT_SHAPE_CUBE) ? RT_FEAT_CUBE : RT_FEAT_COMPLEX;
+            }
         }
     }
     h.xforms.resize(n_xforms);
