@@ -133,7 +133,9 @@ def main():
     scene_desc = workloads.bvh_stress_scene(args.spheres, args.width, args.height)
     params = cfg.params(rng="d0")
     params.tile_rows, params.part_index, params.part_count = args.tile_rows, rank, world
+    t_create = time.perf_counter()
     scene = rt.Scene(scene_desc)  # BVH build + upload: outside the timed region (scene resident in HBM)
+    t_create = time.perf_counter() - t_create
     W, H = args.width, args.height
     # Frames are independent, so F of them are kept in flight: slot s = step % F has its own non-default HIP stream, ray
     # queues (inside the library, per stream) and slice / gather / frame buffers.  Within a slot, kernels, events, the RCCL
@@ -241,7 +243,7 @@ def main():
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
-                       "frames_in_flight": F},
+                       "frames_in_flight": F, "scene_create_ms": round(t_create * 1e3, 1)},
             "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
