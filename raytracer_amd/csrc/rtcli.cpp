@@ -6,6 +6,7 @@
 //   --motion-blur F --fresnel --normals --bvh_testing --tonemap {reinhard|aces|filmic}; unknown arguments are ignored.
 // Added (no counterpart in the reference, whose paths are hard-coded relative to Code/<build>/):
 //   --scene PATH --config PATH --out PATH --texture-root DIR --device N --seed N --d0 --megakernel --pfm PATH
+//   --bvh-builder {sah|lbvh|median}   (rt_set_bvh_builder: host threads / built on the GPU / the reference's topology)
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -33,6 +34,7 @@ static std::string timestamp() {  // main.cpp:35-45
 struct Options {
     bool use_bvh = true, shadows = false, glossy = false, parallel = false, fresnel = false, normals = false;
     bool timing = false, bvh_testing = false, d0 = false, megakernel = false;
+    int bvh_builder = RT_BVH_DEFAULT;
     int run_count = 1, tonemap = 0, device = 0;
     bool have_aa = false, have_exposure = false, have_shutter = false;
     int aa = 1;
@@ -91,6 +93,10 @@ int main(int argc, char* argv[]) {
             else if (a == "--seed" && i + 1 < argc) o.seed = std::stoull(argv[++i]);
             else if (a == "--d0") o.d0 = true;
             else if (a == "--megakernel") o.megakernel = true;
+            else if (a == "--bvh-builder" && i + 1 < argc) {
+                const std::string b = argv[++i];
+                o.bvh_builder = b == "lbvh" ? RT_BVH_LBVH : b == "median" ? RT_BVH_MEDIAN : b == "sah" ? RT_BVH_SAH : RT_BVH_DEFAULT;
+            }
             else if (a == "--pfm" && i + 1 < argc) o.pfm_path = argv[++i];   // also write the linear (pre tone map) frame
         } catch (const std::exception&) {
             std::cerr << "Error: Invalid value for " << a << " flag." << std::endl;
@@ -115,6 +121,7 @@ int main(int argc, char* argv[]) {
     p.seed = o.seed;
     p.schedule = o.megakernel ? RT_SCHEDULE_MEGAKERNEL : RT_SCHEDULE_WAVEFRONT;
 
+    (void)rt_set_bvh_builder(o.bvh_builder);
     if (rt_init(o.device) != RT_OK) {
         std::cerr << "An error occurred: " << rt_last_error() << std::endl;
         return 1;

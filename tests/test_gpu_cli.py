@@ -32,6 +32,22 @@ def test_rtcli_renders_golden(tmp_path):
     assert mx <= 1 and nd <= 0.01 * img.size
 
 
+def test_rtcli_bvh_builder_flag(tmp_path):
+    """--bvh-builder lbvh: the hierarchy built on the GPU, the same picture."""
+    name = "bvh_100_shaded"
+    outs = []
+    for builder in ("sah", "lbvh"):
+        out = str(tmp_path / (builder + ".ppm"))
+        cmd = [os.path.join(ROOT, "raytracer_amd", "rtcli"), "--scene", os.path.join(helpers.GOLD, "scenes", name + ".txt"),
+               "--config", os.path.join(helpers.GOLD, "configs", name + ".json"), "--texture-root", os.path.join(helpers.GOLD, "scenes"),
+               "--out", out, "--d0", "--bvh-builder", builder] + helpers.MANIFEST[name]["flags"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert p.returncode == 0, p.stdout[-2000:]
+        outs.append(rt.read_ppm(out))
+    golden = np.load(os.path.join(helpers.GOLD, "images", name + ".npz"))["image"]
+    assert np.array_equal(outs[0], outs[1]) and helpers.diff_stats(outs[1], golden)[0] <= 1
+
+
 def test_rtcli_missing_scene_fails(tmp_path):
     p = subprocess.run([os.path.join(ROOT, "raytracer_amd", "rtcli"), "--scene", "/nonexistent.txt", "--config", "/nonexistent.json"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
