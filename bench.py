@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=8,
                     help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI; the measured configuration) or gloo "
+                    "(rehearsal of the multi-rank control flow with the ranks sharing the visible GPUs; slices are staged through the host)")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the same frame")
     ap.add_argument("--cpu-passes", type=int, default=18, help="CPU baseline: frames rendered (sized for ~10 s of CPU work on 16 threads)")
     return ap.parse_args()
@@ -123,10 +125,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     rt.init(local_rank)
 
     cfg = workloads.default_config()
@@ -216,6 +223,19 @@ def main():
         traverse_ms, launches_alone = traverse_ms_in_flight, launches
     if world > 1:
         dist.barrier()
+    # outside the timed region: the frame assembled from the ranks' slices against the same frame rendered whole on rank 0
+    frame_ok = None
+    if world > 1:
+        step(slot=0)
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            whole = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+            p1 = params.copy()
+            p1.part_count, p1.part_index = 1, 0
+            scene.render_device(p1, whole.data_ptr(), stream=streams[0].cuda_stream)
+            torch.cuda.synchronize(dev)
+            frame_ok = bool(torch.equal(whole, gathers[0].frame))
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -238,12 +258,13 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: %d random ellipsoids (default_rng(12345)), %dx%d, Whitted 1 spp, default flags, BVH on"
                                    % (args.spheres, W, H),
-                       "partition": "interleaved row tiles of %d rows over %d GPU(s), u8 slices gathered to rank 0 (RCCL)"
-                                    % (args.tile_rows, world),
+                       "partition": "interleaved row tiles of %d rows over %d GPU(s), u8 slices gathered to rank 0 (%s)"
+                                    % (args.tile_rows, world, "RCCL" if args.backend == "nccl" else args.backend + " REHEARSAL, not a measurement"),
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
-                       "frames_in_flight": F, "scene_create_ms": round(t_create * 1e3, 1)},
+                       "frames_in_flight": F, "scene_create_ms": round(t_create * 1e3, 1),
+                       "gathered_frame_equals_whole_frame": frame_ok},
             "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

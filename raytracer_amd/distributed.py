@@ -49,7 +49,15 @@ class FrameGather:
         """Collective: call on every rank after its slice has been written.  Returns the frame on rank 0, else None."""
         if self.world == 1:
             return self.slice[: self.height]
-        dist.gather(self.slice, self.gathered, dst=0)
+        if self.slice.is_cuda and dist.get_backend() == "gloo":
+            # gloo gathers host tensors only (rehearsals of the multi-rank path on a box with fewer GPUs than ranks)
+            host = [torch.empty(self.slice.shape, dtype=torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(self.slice.cpu(), host, dst=0)
+            if self.rank == 0:
+                for view, part in zip(self.gathered, host):
+                    view.copy_(part)
+        else:
+            dist.gather(self.slice, self.gathered, dst=0)
         if self.rank == 0:
             torch.index_select(self.gather_buffer, 0, self.index, out=self.frame)
             return self.frame
