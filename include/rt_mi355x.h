@@ -241,12 +241,15 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
  *                  8-bit quantisation in HIP kernels.  Milliseconds for 10^6 shapes; falls back
  *                  to RT_BVH_SAH when the tree would be deeper than the traversal stack (32 4-wide levels).
  *   RT_BVH_MEDIAN  the reference's own topology (A/B runs)
- *   RT_BVH_DEFAULT environment variable RT_BVH_BUILDER = sah | lbvh | median, else SAH
+ *   RT_BVH_SAH_GPU the same binned-SAH tree as RT_BVH_SAH, built on the GPU (node for node the host's tree unless a span of
+ *                  more than two shapes cannot be split by bins; falls back like RT_BVH_LBVH)
+ *   RT_BVH_DEFAULT environment variable RT_BVH_BUILDER = sah | lbvh | sah_gpu | median, else SAH
  * The reference has one builder, on the host (bvh.cpp:32-92). */
 #define RT_BVH_DEFAULT -1
 #define RT_BVH_SAH      0
 #define RT_BVH_LBVH     1
 #define RT_BVH_MEDIAN   2
+#define RT_BVH_SAH_GPU  3   /* the binned-SAH tree of RT_BVH_SAH built on the GPU, level by level over all spans (bvh_sah.hip) */
 int rt_set_bvh_builder(int builder);
 /* How a device scene was built, and its node array copied back to the host (layout: rt_bvh_device_image), for tests
  * of the device builders.  nodes_out: room for max_nodes nodes or NULL; info_out may be NULL. */

@@ -209,7 +209,7 @@ def shutdown():
     lib.rt_shutdown()
 
 
-BVH_BUILDERS = {"default": -1, "sah": 0, "lbvh": 1, "median": 2}   # RT_BVH_* of rt_mi355x.h
+BVH_BUILDERS = {"default": -1, "sah": 0, "lbvh": 1, "median": 2, "sah_gpu": 3}   # RT_BVH_* of rt_mi355x.h
 
 
 def set_bvh_builder(name):

@@ -259,6 +259,7 @@ static int chosen_builder() {
     const char* e = std::getenv("RT_BVH_BUILDER");
     if (e && std::string(e) == "median") return RT_BVH_MEDIAN;
     if (e && std::string(e) == "lbvh") return RT_BVH_LBVH;
+    if (e && std::string(e) == "sah_gpu") return RT_BVH_SAH_GPU;
     return RT_BVH_SAH;
 }
 static double max_camera_coordinate(const RtSceneDesc& desc) {
@@ -402,13 +403,14 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     DNode4* d_nodes = nullptr;
     Bvh4 b32;
     sc->builder = chosen_builder();
-    if (sc->builder == RT_BVH_LBVH && desc->n_shapes >= 2) {
+    if ((sc->builder == RT_BVH_LBVH || sc->builder == RT_BVH_SAH_GPU) && desc->n_shapes >= 2) {
         const std::vector<Box> boxes = permuted_boxes(sc->bvh.shape_boxes, sc->bvh.order);
         clock.lap("primitive boxes");
         DeviceBvh4 dev4;
         hipError_t herr = hipSuccess;
-        const LbvhStatus st = build_lbvh_device(boxes, sc->bvh.root_box, max_camera_coordinate(*desc), g_dev.stream, &dev4, &herr);
-        clock.lap("device LBVH (with upload)");
+        const LbvhStatus st = build_lbvh_device(boxes, sc->bvh.root_box, max_camera_coordinate(*desc), g_dev.stream, &dev4, &herr,
+                                                sc->builder == RT_BVH_SAH_GPU);
+        clock.lap("device hierarchy (with upload)");
         if (st == LbvhStatus::device_error) return fail(RT_ERR_DEVICE, std::string("device BVH build: ") + hipGetErrorString(herr));
         if (st == LbvhStatus::ok) {
             d_nodes = dev4.nodes;
@@ -424,7 +426,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         } else {
             sc->builder = RT_BVH_SAH;   // deeper than the traversal stack: the host builder bounds its depth
         }
-    } else if (sc->builder == RT_BVH_LBVH) {
+    } else if (sc->builder == RT_BVH_LBVH || sc->builder == RT_BVH_SAH_GPU) {
         sc->builder = RT_BVH_SAH;       // fewer than two shapes: nothing to build
     }
     if (!d_nodes) {
@@ -512,7 +514,7 @@ void rt_scene_destroy(rt_scene_t scene) {
 }
 
 int rt_set_bvh_builder(int builder) {
-    if (builder != RT_BVH_DEFAULT && builder != RT_BVH_SAH && builder != RT_BVH_LBVH && builder != RT_BVH_MEDIAN)
+    if (builder != RT_BVH_DEFAULT && builder != RT_BVH_SAH && builder != RT_BVH_LBVH && builder != RT_BVH_MEDIAN && builder != RT_BVH_SAH_GPU)
         return fail(RT_ERR_INVALID, "unknown BVH builder");
     g_builder = builder;
     return RT_OK;

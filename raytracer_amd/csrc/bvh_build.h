@@ -30,8 +30,15 @@ enum class LbvhStatus {
 };
 
 // boxes: one per primitive, in primitive order (n >= 2); root_box: their union; max_abs_origin: as for to_node4.
+// binned_sah: the binary tree comes from the binned surface-area heuristic (bvh_sah.hip) instead of Morton order.
 LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box, double max_abs_origin, hipStream_t stream,
-                             DeviceBvh4* out, hipError_t* err);
+                             DeviceBvh4* out, hipError_t* err, bool binned_sah = false);
+
+// bvh_sah.hip: the binary tree of host_bvh.cpp: SahBuilder built on the device over d_boxes (n x 6 doubles, primitive
+// order).  d_vals[i] = primitive at leaf position i; interior node k: children d_left[k] / d_right[k] (>= 0 interior,
+// < 0 leaf = ~position), covering positions d_range_lo[k] .. d_range_hi[k].  Synchronises the stream.
+hipError_t sah_binary_tree_device(const double* d_boxes, int n, int max_depth, hipStream_t stream, unsigned* d_vals, int* d_left, int* d_right,
+                                  int* d_range_lo, int* d_range_hi, bool* incomplete);
 
 // The reference's depth-first visit order of the shapes (bvh.cpp:32-92), computed on the device from the shapes' world
 // boxes in scene-file order (bvh_order.hip).  order[k] = scene-file index of the k-th primitive.

@@ -303,7 +303,7 @@ size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 }  // namespace
 
 LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box, double max_abs_origin, hipStream_t stream,
-                             DeviceBvh4* out, hipError_t* err) {
+                             DeviceBvh4* out, hipError_t* err, bool binned_sah) {
     *err = hipSuccess;
     const size_t n = boxes.size();
     if (n < 2 || n > (size_t(1) << 30)) { *err = hipErrorInvalidValue; return LbvhStatus::device_error; }
@@ -389,10 +389,16 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
     LBVH_TRY(hipMemsetAsync(base + o_zero, 0, o_zero_end - o_zero, stream));
     const unsigned gl = static_cast<unsigned>((n + kB - 1) / kB);          // one thread per leaf
     const unsigned gn = static_cast<unsigned>((n - 1 + kB - 1) / kB);      // one thread per interior node
-    hipLaunchKernelGGL(k_lbvh_codes, dim3(gl), dim3(kB), 0, stream, d_boxes, ni, grid, keys_in, vals_in);
-    size_t tb = sort_bytes;
-    LBVH_TRY(rocprim::radix_sort_pairs(d_temp, tb, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream));
-    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(gn), dim3(kB), 0, stream, keys_out, ni, d_left, d_right, d_rlo, d_rhi);
+    if (binned_sah) {
+        bool incomplete = false;
+        LBVH_TRY(sah_binary_tree_device(d_boxes, ni, kMaxBinaryDepth, stream, vals_out, d_left, d_right, d_rlo, d_rhi, &incomplete));
+        if (incomplete) return fail(hipErrorUnknown);
+    } else {
+        hipLaunchKernelGGL(k_lbvh_codes, dim3(gl), dim3(kB), 0, stream, d_boxes, ni, grid, keys_in, vals_in);
+        size_t tb = sort_bytes;
+        LBVH_TRY(rocprim::radix_sort_pairs(d_temp, tb, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream));
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(gn), dim3(kB), 0, stream, keys_out, ni, d_left, d_right, d_rlo, d_rhi);
+    }
     hipLaunchKernelGGL(k_lbvh_leaf_boxes, dim3(gl), dim3(kB), 0, stream, d_boxes, vals_out, ni, d_seg, d_flags);
     for (int k = 1; k < seg_levels.levels; ++k)
         hipLaunchKernelGGL(k_lbvh_seg_level, dim3((unsigned)((seg_levels.count[k] + kB - 1) / kB)), dim3(kB), 0, stream,
@@ -405,7 +411,7 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
     for (int lvl = 1; lvl <= max_levels; ++lvl)
         hipLaunchKernelGGL(k_lbvh_mark, dim3(gn), dim3(kB), 0, stream, ni, lvl, max_levels, d_left, d_right, d_nbox, d_level, d_slots, d_flags);
     hipLaunchKernelGGL(k_lbvh_used, dim3(gn), dim3(kB), 0, stream, ni, d_level, d_used);
-    tb = scan_bytes;
+    size_t tb = scan_bytes;
     LBVH_TRY(rocprim::exclusive_scan(d_temp, tb, d_used, d_widx, 0, n - 1, rocprim::plus<int>(), stream));
     // the number of 4-wide nodes is needed to size the result: the one round trip of the build
     int last[2] = {0, 0};

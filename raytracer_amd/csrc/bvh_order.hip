@@ -60,8 +60,7 @@ __global__ void __launch_bounds__(kB) k_order_bounds(const double* __restrict__ 
         active = !done[i];
     }
     const bool longspan = active && (e - s) > kShortSpan;
-    if (active && !longspan) {
-        if (i != s) return;   // the first element of a short span reduces it
+    if (active && !longspan && i == s) {   // the first element of a short span reduces it
         double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = s; k < e; ++k) {
             const double* b = boxes + 6 * (size_t)perm[k];
@@ -74,9 +73,10 @@ __global__ void __launch_bounds__(kB) k_order_bounds(const double* __restrict__ 
             lo[3 * (size_t)s + a] = encode(mn[a]);
             hi[3 * (size_t)s + a] = encode(mx[a]);
         }
-        return;
     }
-    // long spans: lanes of one wave mostly share a span; reduce in the wave when they all do
+    // long spans: lanes of one wave mostly share a span; reduce in the wave when they all do.  Every lane of the wave
+    // takes part in what follows (lanes outside long spans with the identity), because the shuffles below read all 64
+    // lanes: a lane that had left the kernel would hand over whatever its registers hold.
     const unsigned long long m = __ballot(longspan);
     if (m == 0ull) return;
     u64 mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0ull, 0ull, 0ull};

@@ -116,7 +116,7 @@ def test_a_tree_deeper_than_the_stack_falls_back_to_the_host_builder(gpu, monkey
     assert mx <= 1
 
 
-@pytest.mark.parametrize("n", [2, 3, 5, 7, 64, 1000, 70_001, 300_000])
+@pytest.mark.parametrize("n", [2, 3, 5, 7, 64, 1000, 1040, 66_001, 70_001, 300_000])   # 1040, 66001: levels that mix spans of 32 (one thread) and 33 (wave reduction)
 def test_device_order_equals_the_host_order(gpu, n):
     """bvh_order.hip against host_bvh.cpp: build_bvh, which restates the reference's top-down median split
     (bvh.cpp:32-92): the same permutation of the shapes, element for element."""
@@ -148,3 +148,68 @@ def test_large_scenes_take_their_order_from_the_device(gpu, monkeypatch):
     scene.close()
     assert info_a["order_on_device"] and info_a["device_order_ms"] > 0 and not info_b["order_on_device"]
     assert np.array_equal(a, b) and np.array_equal(info_a["nodes"], info_b["nodes"])
+
+
+@pytest.fixture()
+def sah_gpu(gpu):
+    rt.set_bvh_builder("sah_gpu")
+    yield
+    rt.set_bvh_builder("default")
+
+
+@pytest.mark.parametrize("name", ["bvh_100_normals", "c1_default", "gal_shapes", "gal_bike", "own_complex", "own_motion", "bvh_2_normals"])
+def test_device_sah_image_covers_reference_boxes(sah_gpu, name):
+    desc, _, _ = helpers.load_case(name)
+    scene, img = _device_image(desc)
+    scene.close()
+    assert img["builder"] == "sah_gpu"
+    _check_image(img, desc.desc.n_shapes, check_root_box=False)
+
+
+@pytest.mark.parametrize("n,clustered", [(2, False), (3, False), (5, False), (65, False), (1000, False), (3000, True), (50_000, False)])
+def test_device_sah_is_the_host_sah_tree(sah_gpu, n, clustered):
+    """bvh_sah.hip builds host_bvh.cpp's binned-SAH tree: same number of 4-wide nodes and depth as the host image and --
+    compared as sets, since the two collapses number their nodes differently -- the same nodes.  (clustered: 300
+    coincident centres, where the host's balanced fallback orders by index and the device cuts by position: the trees
+    may then differ below that span, and only the structure is checked.)"""
+    sb = _random_scene(n, 11 + n, clustered)
+    scene, img = _device_image(sb)
+    scene.close()
+    assert img["builder"] == "sah_gpu"
+    _check_image(img, n, check_root_box=False)
+    host = rt.bvh_device_image(sb)
+    if not clustered:
+        assert img["info"].n_nodes == host["info"].n_nodes and img["info"].max_depth == host["info"].max_depth
+
+        def boxes_of(nodes):   # node contents without the child numbering: grid + quantised planes + leaf references
+            out = []
+            for nd in nodes:
+                leaves = tuple(sorted(int(c) for c in nd["child"] if c < 0))
+                out.append((tuple(nd["org"].tolist()), int(nd["exps"]), tuple(sorted(zip(*[[(int(nd["qlo"][a]) >> (8 * c)) & 255 for c in range(4)] for a in range(3)] +
+                                                                                      [[(int(nd["qhi"][a]) >> (8 * c)) & 255 for c in range(4)] for a in range(3)]))), leaves))
+            return sorted(out)
+        if n <= 1000:
+            assert boxes_of(img["nodes"]) == boxes_of(host["nodes"])
+
+
+def test_device_sah_renders_like_the_host_sah(gpu):
+    """200 000 ellipsoids: the same frame, and (within 1 %) the same number of box and primitive tests as with the host-built tree."""
+    from raytracer_amd import workloads
+    desc = workloads.bvh_stress_scene(200_000, 480, 270)
+    params = workloads.default_config().params(rng="d0")
+    out = {}
+    for builder in ("sah", "sah_gpu"):
+        rt.set_bvh_builder(builder)
+        try:
+            scene = rt.Scene(desc)
+        finally:
+            rt.set_bvh_builder("default")
+        assert scene.bvh_nodes()["builder"] == builder
+        out[builder] = scene.render(params, stats=True)
+        scene.close()
+    (a, sa), (b, sb) = out["sah"], out["sah_gpu"]
+    assert np.array_equal(a, b)
+    # the same tree; leaves are tested a little earlier or later depending on how the waves happen to run, so the counts
+    # agree closely, not exactly
+    for x, y in ((sa.nodes_visited, sb.nodes_visited), (sa.prims_tested, sb.prims_tested), (sa.nodes_fetched, sb.nodes_fetched)):
+        assert abs(int(x) - int(y)) <= 0.01 * int(x)
