@@ -31,6 +31,7 @@ namespace {
 constexpr int kB = 256;
 constexpr int kBins = 32;        // host_bvh.cpp: SahBuilder::kBins
 constexpr int kShortSpan = 64;   // spans up to this size are binned by one thread
+constexpr int kTinySpan = 12;    // spans up to this size try every primitive's bin directly (no bin arrays)
 constexpr int kTableWords = 3 * kBins * 3;   // per table: min or max of 3 axes x 32 bins x 3 coordinates
 
 typedef unsigned long long u64;
@@ -174,24 +175,52 @@ __device__ __forceinline__ void sweep_axis(const int axis, BoxAt&& bb, CountAt&&
     }
 }
 
-// Decision per span, at its first position: axis >= 0 and bin = split below that bin boundary; axis -1 = cut the span in
-// halves by position; axis -2 = a pair.
+// Best split of one axis per span, at [3 * first position + axis]: cost (+inf = none) and the bin below whose upper
+// boundary the span is cut.  One thread per (span, axis); k_sah_pick then takes the cheapest axis, the lowest on equal
+// cost, as the host's loop over the axes does.  Pairs are marked in dec_axis directly.
 __global__ void __launch_bounds__(kB) k_sah_choose_short(const double* __restrict__ boxes, const int* __restrict__ perm, const int n,
                                                          const Spans sp, const u64* __restrict__ lo, const u64* __restrict__ hi,
-                                                         int* __restrict__ dec_axis, int* __restrict__ dec_bin) {
-    const int i = blockIdx.x * kB + threadIdx.x;
+                                                         double* __restrict__ axis_cost, int* __restrict__ axis_bin) {
+    const int j = blockIdx.x * kB + threadIdx.x;
+    const int i = j / 3, axis = j - 3 * i;
     if (i >= n || sp.done[i]) return;
     const int s = sp.start[i], e = sp.end[i], m = e - s;
-    if (i != s || m > kShortSpan) return;
-    if (m == 2) { dec_axis[s] = -2; dec_bin[s] = 0; return; }
-    double bbox[kBins][6];
-    unsigned count[kBins];
+    if (i != s || m > kShortSpan || m == 2) return;
     double best_cost = INFINITY;
     int best_axis = -1, best_bin = -1;
-    const int depth_left = sp.dleft[i];
-    for (int axis = 0; axis < 3; ++axis) {
-        const double l = decode(lo[3 * (size_t)s + axis]), ext = decode(hi[3 * (size_t)s + axis]) - l;
-        if (!(ext > 0.0) || !isfinite(ext)) continue;
+    const double l = decode(lo[3 * (size_t)s + axis]), ext = decode(hi[3 * (size_t)s + axis]) - l;
+    if (ext > 0.0 && isfinite(ext) && m <= kTinySpan) {
+        // A handful of primitives occupy a handful of bins: instead of filling and sweeping 32 bins in scratch memory,
+        // every primitive's bin is tried as the split (left = bins up to it) with the two boxes joined from scratch.
+        // The sweep keeps the first of equally cheap bins; taking the smallest (cost, bin) is the same choice, and
+        // the cost is the sweep's, bit for bit (the same boxes, the same arithmetic).
+        const double scale = kBins / ext;
+        const int depth_left = sp.dleft[i];
+        for (int c = s; c < e; ++c) {
+            const int B = bin_of(centre_of(boxes + 6 * (size_t)perm[c], axis), l, scale);
+            double lb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            double rb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            unsigned nl = 0, nr = 0;
+            for (int k = s; k < e; ++k) {
+                const double* pb = boxes + 6 * (size_t)perm[k];
+                const bool left = bin_of(centre_of(pb, axis), l, scale) <= B;
+                double* dst = left ? lb : rb;
+                for (int q = 0; q < 3; ++q) {
+                    dst[q] = fmin(dst[q], pb[q]);
+                    dst[3 + q] = fmax(dst[3 + q], pb[3 + q]);
+                }
+                if (left) ++nl; else ++nr;
+            }
+            if (nl == 0 || nr == 0) continue;
+            if (ceil_log2(max(nl, nr)) > depth_left - 1) continue;
+            const double lx = lb[3] - lb[0], ly = lb[4] - lb[1], lz = lb[5] - lb[2];
+            const double rx = rb[3] - rb[0], ry = rb[4] - rb[1], rz = rb[5] - rb[2];
+            const double cost = (lx * ly + ly * lz + lz * lx) * (double)nl + (rx * ry + ry * rz + rz * rx) * (double)nr;
+            if (cost < best_cost || (cost == best_cost && B < best_bin)) { best_cost = cost; best_axis = axis; best_bin = B; }
+        }
+    } else if (ext > 0.0 && isfinite(ext)) {
+        double bbox[kBins][6];
+        unsigned count[kBins];
         const double scale = kBins / ext;
         for (int b = 0; b < kBins; ++b) {
             count[b] = 0;
@@ -207,10 +236,27 @@ __global__ void __launch_bounds__(kB) k_sah_choose_short(const double* __restric
             ++count[b];
         }
         sweep_axis(axis, [&](int b, double* v) { for (int k = 0; k < 6; ++k) v[k] = bbox[b][k]; }, [&](int b) { return count[b]; },
-                   depth_left, best_cost, best_axis, best_bin);
+                   sp.dleft[i], best_cost, best_axis, best_bin);
     }
-    dec_axis[s] = best_axis;
-    dec_bin[s] = best_bin;
+    axis_cost[3 * (size_t)s + axis] = best_cost;
+    axis_bin[3 * (size_t)s + axis] = best_bin;
+}
+
+// Decision per span, at its first position: axis >= 0 and bin = split below that bin boundary; axis -1 = cut the span in
+// halves by position; axis -2 = a pair.
+__global__ void __launch_bounds__(kB) k_sah_pick(const int n, const Spans sp, const double* __restrict__ axis_cost, const int* __restrict__ axis_bin,
+                                                 int* __restrict__ dec_axis, int* __restrict__ dec_bin) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n || sp.done[i] || i != sp.start[i]) return;
+    if (sp.end[i] - i == 2) { dec_axis[i] = -2; dec_bin[i] = 0; return; }
+    double best_cost = INFINITY;
+    int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+        const double c = axis_cost[3 * (size_t)i + axis];
+        if (c < best_cost) { best_cost = c; best_axis = axis; best_bin = axis_bin[3 * (size_t)i + axis]; }
+    }
+    dec_axis[i] = best_axis;
+    dec_bin[i] = best_bin;
 }
 
 // Tables of the long spans: table t = start >> 6 (long spans start more than 64 positions apart).
@@ -272,27 +318,25 @@ __global__ void __launch_bounds__(kB) k_sah_bin_long(const double* __restrict__ 
 
 __global__ void __launch_bounds__(kB) k_sah_choose_long(const int n, const Spans sp, const u64* __restrict__ lo, const u64* __restrict__ hi,
                                                         const u64* __restrict__ tmin, const u64* __restrict__ tmax,
-                                                        const unsigned* __restrict__ tcnt, int* __restrict__ dec_axis, int* __restrict__ dec_bin) {
-    const int i = blockIdx.x * kB + threadIdx.x;
+                                                        const unsigned* __restrict__ tcnt, double* __restrict__ axis_cost, int* __restrict__ axis_bin) {
+    const int j = blockIdx.x * kB + threadIdx.x;
+    const int i = j / 3, axis = j - 3 * i;
     if (i >= n || sp.done[i]) return;
     const int s = sp.start[i], m = sp.end[i] - s;
     if (i != s || m <= kShortSpan) return;
     const size_t t = (size_t)(s >> 6);
     double best_cost = INFINITY;
     int best_axis = -1, best_bin = -1;
-    const int depth_left = sp.dleft[i];
-    for (int axis = 0; axis < 3; ++axis) {
-        const double ext = decode(hi[3 * (size_t)s + axis]) - decode(lo[3 * (size_t)s + axis]);
-        if (!(ext > 0.0) || !isfinite(ext)) continue;
+    const double ext = decode(hi[3 * (size_t)s + axis]) - decode(lo[3 * (size_t)s + axis]);
+    if (ext > 0.0 && isfinite(ext))
         sweep_axis(axis,
                    [&](int b, double* v) {
                        const size_t w = t * kTableWords + (size_t)(axis * kBins + b) * 3;
                        for (int k = 0; k < 3; ++k) { v[k] = decode(tmin[w + k]); v[3 + k] = decode(tmax[w + k]); }
                    },
-                   [&](int b) { return tcnt[t * 3 * kBins + axis * kBins + b]; }, depth_left, best_cost, best_axis, best_bin);
-    }
-    dec_axis[s] = best_axis;
-    dec_bin[s] = best_bin;
+                   [&](int b) { return tcnt[t * 3 * kBins + axis * kBins + b]; }, sp.dleft[i], best_cost, best_axis, best_bin);
+    axis_cost[3 * (size_t)s + axis] = best_cost;
+    axis_bin[3 * (size_t)s + axis] = best_bin;
 }
 
 // left[i] = 1 when the primitive at position i goes to the left half of its span (0 for final positions).
@@ -404,6 +448,7 @@ hipError_t sah_binary_tree_device(const double* d_boxes, int n, int max_depth, h
     const size_t o_lturns = carve(N * sizeof(int)), o_dleft = carve(N * sizeof(int));
     const size_t o_lo = carve(N * 3 * sizeof(u64)), o_hi = carve(N * 3 * sizeof(u64));
     const size_t o_axis = carve(N * sizeof(int)), o_bin = carve(N * sizeof(int)), o_nleft = carve(N * sizeof(int));
+    const size_t o_acost = carve(N * 3 * sizeof(double)), o_abin = carve(N * 3 * sizeof(int));
     const size_t o_side = carve(N * sizeof(int)), o_rank = carve(N * sizeof(int));
     const size_t o_tmin = carve(tables * kTableWords * sizeof(u64)), o_tmax = carve(tables * kTableWords * sizeof(u64));
     const size_t o_tcnt = carve(tables * 3 * kBins * sizeof(unsigned));
@@ -426,6 +471,8 @@ hipError_t sah_binary_tree_device(const double* d_boxes, int n, int max_depth, h
     int* d_axis = reinterpret_cast<int*>(base + o_axis);
     int* d_bin = reinterpret_cast<int*>(base + o_bin);
     int* d_nleft = reinterpret_cast<int*>(base + o_nleft);
+    double* d_acost = reinterpret_cast<double*>(base + o_acost);
+    int* d_abin = reinterpret_cast<int*>(base + o_abin);
     int* d_side = reinterpret_cast<int*>(base + o_side);
     int* d_rank = reinterpret_cast<int*>(base + o_rank);
     u64* d_tmin = reinterpret_cast<u64*>(base + o_tmin);
@@ -434,7 +481,7 @@ hipError_t sah_binary_tree_device(const double* d_boxes, int n, int max_depth, h
     unsigned* d_flags = reinterpret_cast<unsigned*>(base + o_flags);
     void* d_temp = base + o_temp;
 
-    const unsigned g = static_cast<unsigned>((N + kB - 1) / kB);
+    const unsigned g = static_cast<unsigned>((N + kB - 1) / kB), g3 = static_cast<unsigned>((3 * N + kB - 1) / kB);
     SAH_TRY(hipMemsetAsync(d_flags, 0, 4 * sizeof(unsigned), stream));
     hipLaunchKernelGGL(k_sah_init, dim3(g), dim3(kB), 0, stream, n, depth, d_perm, sp);
     unsigned flags[4] = {0, 0, 0, 0};
@@ -446,9 +493,10 @@ hipError_t sah_binary_tree_device(const double* d_boxes, int n, int max_depth, h
         SAH_TRY(hipMemsetAsync(d_tcnt, 0x00, tables * 3 * kBins * sizeof(unsigned), stream));
         SAH_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), stream));
         hipLaunchKernelGGL(k_sah_centre_bounds, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi);
-        hipLaunchKernelGGL(k_sah_choose_short, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_axis, d_bin);
+        hipLaunchKernelGGL(k_sah_choose_short, dim3(g3), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_acost, d_abin);
         hipLaunchKernelGGL(k_sah_bin_long, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_tmin, d_tmax, d_tcnt);
-        hipLaunchKernelGGL(k_sah_choose_long, dim3(g), dim3(kB), 0, stream, n, sp, d_lo, d_hi, d_tmin, d_tmax, d_tcnt, d_axis, d_bin);
+        hipLaunchKernelGGL(k_sah_choose_long, dim3(g3), dim3(kB), 0, stream, n, sp, d_lo, d_hi, d_tmin, d_tmax, d_tcnt, d_acost, d_abin);
+        hipLaunchKernelGGL(k_sah_pick, dim3(g), dim3(kB), 0, stream, n, sp, d_acost, d_abin, d_axis, d_bin);
         hipLaunchKernelGGL(k_sah_side, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_axis, d_bin, d_side);
         size_t tb = scan_bytes;
         SAH_TRY(rocprim::exclusive_scan(d_temp, tb, d_side, d_rank, 0, N, rocprim::plus<int>(), stream));
