@@ -236,14 +236,15 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
  * afterwards).  The primitive numbering -- the reference's depth-first visit order (bvh.cpp:32-92), which decides
  * equal-distance hits -- always comes from the host pass; the closest hit does not depend on the hierarchy, so all
  * builders yield the same frames.
- *   RT_BVH_SAH     binned surface-area heuristic on host threads (default; fewest node visits per ray)
+ *   RT_BVH_SAH     binned surface-area heuristic on host threads (fewest node visits per ray)
  *   RT_BVH_LBVH    built on the GPU: Morton order, radix sort, binary radix tree, segment-tree boxes, 4-wide collapse and
  *                  8-bit quantisation in HIP kernels.  Milliseconds for 10^6 shapes; falls back
  *                  to RT_BVH_SAH when the tree would be deeper than the traversal stack (32 4-wide levels).
  *   RT_BVH_MEDIAN  the reference's own topology (A/B runs)
  *   RT_BVH_SAH_GPU the same binned-SAH tree as RT_BVH_SAH, built on the GPU (node for node the host's tree unless a span of
  *                  more than two shapes cannot be split by bins; falls back like RT_BVH_LBVH)
- *   RT_BVH_DEFAULT environment variable RT_BVH_BUILDER = sah | lbvh | sah_gpu | median, else SAH
+ *   RT_BVH_DEFAULT environment variable RT_BVH_BUILDER = sah | lbvh | sah_gpu | median, else the SAH tree: RT_BVH_SAH_GPU
+ *                  from 65536 shapes, RT_BVH_SAH below
  * The reference has one builder, on the host (bvh.cpp:32-92). */
 #define RT_BVH_DEFAULT -1
 #define RT_BVH_SAH      0

@@ -213,8 +213,9 @@ BVH_BUILDERS = {"default": -1, "sah": 0, "lbvh": 1, "median": 2, "sah_gpu": 3}  
 
 
 def set_bvh_builder(name):
-    """Builder of the hierarchy the device traverses, for scenes created afterwards: "sah" (host threads, default),
-    "lbvh" (built on the GPU), "median" (the reference's topology), "default" (environment RT_BVH_BUILDER, else sah)."""
+    """Builder of the hierarchy the device traverses, for scenes created afterwards: "sah" (host threads), "sah_gpu" (the same
+    tree built on the GPU), "lbvh" (Morton-order tree built on the GPU), "median" (the reference's topology), "default"
+    (environment RT_BVH_BUILDER, else the SAH tree: on the GPU from 65536 shapes, on host threads below)."""
     _check(lib.rt_set_bvh_builder(BVH_BUILDERS[name]))
 
 

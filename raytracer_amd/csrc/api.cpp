@@ -252,15 +252,17 @@ struct BuildClock {
 };
 
 // Builder of the hierarchy the device traverses: rt_set_bvh_builder(), else RT_BVH_BUILDER = sah | lbvh | median, else SAH.
-constexpr int kDeviceOrderMinShapes = 65536;   // below this the host pass takes a few milliseconds
+constexpr int kDeviceOrderMinShapes = 65536;   // below this the host passes (order, SAH tree) take a few milliseconds
 static int g_builder = -1;
-static int chosen_builder() {
+static int chosen_builder(int n_shapes = 0) {
     if (g_builder >= 0) return g_builder;
     const char* e = std::getenv("RT_BVH_BUILDER");
     if (e && std::string(e) == "median") return RT_BVH_MEDIAN;
     if (e && std::string(e) == "lbvh") return RT_BVH_LBVH;
     if (e && std::string(e) == "sah_gpu") return RT_BVH_SAH_GPU;
-    return RT_BVH_SAH;
+    if (e && std::string(e) == "sah") return RT_BVH_SAH;
+    // default: the binned-SAH tree -- built on the device for large scenes (the same tree, bvh_sah.hip), else on host threads
+    return n_shapes >= kDeviceOrderMinShapes ? RT_BVH_SAH_GPU : RT_BVH_SAH;
 }
 static double max_camera_coordinate(const RtSceneDesc& desc) {
     double m = 0.0;
@@ -402,7 +404,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     // The hierarchy the device traverses: built on the GPU (RT_BVH_LBVH) or on host threads.
     DNode4* d_nodes = nullptr;
     Bvh4 b32;
-    sc->builder = chosen_builder();
+    sc->builder = chosen_builder(desc->n_shapes);
     if ((sc->builder == RT_BVH_LBVH || sc->builder == RT_BVH_SAH_GPU) && desc->n_shapes >= 2) {
         const std::vector<Box> boxes = permuted_boxes(sc->bvh.shape_boxes, sc->bvh.order);
         clock.lap("primitive boxes");

@@ -392,7 +392,12 @@ LbvhStatus build_lbvh_device(const std::vector<Box>& boxes, const Box& root_box,
     if (binned_sah) {
         bool incomplete = false;
         LBVH_TRY(sah_binary_tree_device(d_boxes, ni, kMaxBinaryDepth, stream, vals_out, d_left, d_right, d_rlo, d_rhi, &incomplete));
-        if (incomplete) return fail(hipErrorUnknown);
+        if (incomplete) {   // spans left unsplit after all levels: cannot happen within the depth bound; the host builder takes over
+            (void)hipFree(base);
+            (void)hipEventDestroy(ev0);
+            (void)hipEventDestroy(ev1);
+            return LbvhStatus::too_deep;
+        }
     } else {
         hipLaunchKernelGGL(k_lbvh_codes, dim3(gl), dim3(kB), 0, stream, d_boxes, ni, grid, keys_in, vals_in);
         size_t tb = sort_bytes;

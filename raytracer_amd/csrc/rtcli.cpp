@@ -6,7 +6,7 @@
 //   --motion-blur F --fresnel --normals --bvh_testing --tonemap {reinhard|aces|filmic}; unknown arguments are ignored.
 // Added (no counterpart in the reference, whose paths are hard-coded relative to Code/<build>/):
 //   --scene PATH --config PATH --out PATH --texture-root DIR --device N --seed N --d0 --megakernel --pfm PATH
-//   --bvh-builder {sah|lbvh|median}   (rt_set_bvh_builder: host threads / built on the GPU / the reference's topology)
+//   --bvh-builder {sah|sah_gpu|lbvh|median}   (rt_set_bvh_builder: host threads / built on the GPU / the reference's topology)
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -95,7 +95,7 @@ int main(int argc, char* argv[]) {
             else if (a == "--megakernel") o.megakernel = true;
             else if (a == "--bvh-builder" && i + 1 < argc) {
                 const std::string b = argv[++i];
-                o.bvh_builder = b == "lbvh" ? RT_BVH_LBVH : b == "median" ? RT_BVH_MEDIAN : b == "sah" ? RT_BVH_SAH : RT_BVH_DEFAULT;
+                o.bvh_builder = b == "lbvh" ? RT_BVH_LBVH : b == "median" ? RT_BVH_MEDIAN : b == "sah" ? RT_BVH_SAH : b == "sah_gpu" ? RT_BVH_SAH_GPU : RT_BVH_DEFAULT;
             }
             else if (a == "--pfm" && i + 1 < argc) o.pfm_path = argv[++i];   // also write the linear (pre tone map) frame
         } catch (const std::exception&) {
