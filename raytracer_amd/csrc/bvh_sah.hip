@@ -31,7 +31,10 @@ namespace {
 constexpr int kB = 256;
 constexpr int kBins = 32;        // host_bvh.cpp: SahBuilder::kBins
 constexpr int kShortSpan = 64;   // spans up to this size are binned by one thread
-constexpr int kTinySpan = 12;    // spans up to this size try every primitive's bin directly (no bin arrays)
+#ifndef RT_SAH_TINY
+#define RT_SAH_TINY 12
+#endif
+constexpr int kTinySpan = RT_SAH_TINY;    // spans up to this size try every primitive's bin directly (no bin arrays)
 constexpr int kTableWords = 3 * kBins * 3;   // per table: min or max of 3 axes x 32 bins x 3 coordinates
 
 typedef unsigned long long u64;
