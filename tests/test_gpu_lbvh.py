@@ -213,3 +213,25 @@ def test_device_sah_renders_like_the_host_sah(gpu):
     # agree closely, not exactly
     for x, y in ((sa.nodes_visited, sb.nodes_visited), (sa.prims_tested, sb.prims_tested), (sa.nodes_fetched, sb.nodes_fetched)):
         assert abs(int(x) - int(y)) <= 0.01 * int(x)
+
+
+def test_large_degenerate_scene_on_the_default_path(gpu):
+    """70 000 shapes in five tight clusters, 7 000 of them with one and the same centre: the device order pass refuses
+    (ties at splits -> host pass), the device SAH build cuts the coincident span by position; the hierarchy must still
+    cover every shape, and the frame must be the host-built one."""
+    sb = _random_scene(70_000, 77, True)
+    params = rt.Config(text="{}").params(rng="d0", normals=1)
+    out = {}
+    for builder in ("default", "sah"):
+        rt.set_bvh_builder(builder)
+        try:
+            scene = rt.Scene(sb)
+        finally:
+            rt.set_bvh_builder("default")
+        img = scene.bvh_nodes()
+        img["prim_boxes"] = rt.bvh_device_image(sb)["prim_boxes"]
+        out[builder] = (scene.render(params), img)
+        scene.close()
+    assert out["default"][1]["builder"] == "sah_gpu" and not out["default"][1]["order_on_device"]
+    _check_image(out["default"][1], 70_000, check_root_box=False)
+    assert np.array_equal(out["default"][0], out["sah"][0])
