@@ -31,6 +31,8 @@ struct WavefrontWorkspace {
     size_t events_used = 0;
     int compute_units = 256;
     int rays_per_lane = 2;               // traversal grid sizing (RT_RAYS_PER_LANE)
+    size_t grow = 1;                     // queue headroom factor, raised once when a frame's ray tree outgrew the queues
+    size_t grown_capacity = 0;           // ... and the capacity that was granted then (may exceed the default maximum)
     bool levels_overflowed = false;      // a frame's ray tree outgrew the queues when its levels were enqueued without round trips
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);

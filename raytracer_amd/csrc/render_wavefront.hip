@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -719,6 +720,7 @@ constexpr int kFull = kAnalytic | RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_EN
 constexpr size_t kMaxTimedEvents = 8192;   // start/stop events kept per workspace until they are collected
 constexpr size_t kMinQueueRays = size_t(1) << 16;
 constexpr size_t kDefaultMaxQueueRays = size_t(1) << 26;   // 9.7 GB per queue (rays + hit records)
+constexpr size_t kGrownMaxQueueRays = size_t(1) << 28;     // after a frame's ray tree outgrew the queues (one-chunk frames only)
 
 struct Driver {
     const DScene& S;
@@ -729,6 +731,7 @@ struct Driver {
     int traverse_blocks;
     unsigned long long rays_traced = 0;
     bool may_emit = true;   // false: no launch of k_shade can queue a ray
+    size_t max_capacity = 0;   // RT_QUEUE_RAYS
     uint8_t* direct = nullptr;   // see EmitCtx::direct
     hipError_t err = hipSuccess;
 
@@ -847,7 +850,23 @@ struct Driver {
             ok(hipStreamSynchronize(stream));
         }
         if (err != hipSuccess) { release(q); return 0; }
-        if (res[1]) { release(q); ws.levels_overflowed = true; return 1; }
+        if (res[1]) {
+            // A level outgrew its queue.  At most twice per workspace the queues are doubled for the frames to come
+            // (deep ray trees of glass scenes peak well above their first level) -- up to RT_QUEUE_RAYS when that is set,
+            // else up to 2^28 rays, and only while the device has room for eight such queues; if that was not enough
+            // either, this stream's frames stay on the level-by-level path.
+            release(q);
+            size_t free_bytes = 0, total_bytes = 0;
+            (void)hipMemGetInfo(&free_bytes, &total_bytes);
+            const size_t bigger = std::min(ws.capacity * 2, max_capacity);
+            if (ws.grow <= 2 && bigger > ws.capacity && free_bytes >= 8 * bigger * (sizeof(RayRec) + sizeof(HitRec))) {
+                ws.grow *= 2;
+                ws.grown_capacity = bigger;
+            } else {
+                ws.levels_overflowed = true;
+            }
+            return 1;
+        }
         rays_traced += n0 + total;   // level 0 was launched with a host count
         if (res[0] != 0u) process(q, res[0], level);
         else release(q);
@@ -908,18 +927,22 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     // 9.7 GB per queue; a frame that needs more is rendered in chunks of rows x samples and batches of rays).  Large
     // queues mean few batches, i.e. few launches and few host round trips per level: HBM is there to be used.
     const bool may_emit = !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
+    size_t max_queue_rays = 0;
     {
         const char* env = getenv("RT_QUEUE_RAYS");
         const size_t env_cap = env ? strtoull(env, nullptr, 10) : 0;
-        const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : kDefaultMaxQueueRays, size_t(1) << 31);   // slots are 32-bit
+        const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : std::max(kDefaultMaxQueueRays, ws.grown_capacity), size_t(1) << 31);   // slots are 32-bit
         size_t fan = 1;
         if (may_emit) {
             const size_t refl = (params.max_depth < params.max_bounces) ? 1 : (size_t)std::max(params.glossy_samples, 1);
             fan = refl + 1 + (params.shadows ? 2ull * (size_t)scene.n_lights * (size_t)params.shadow_samples : 0ull);
         }
         size_t want = kMinQueueRays;
-        while (want < max_cap && want < npix * (size_t)params.spp * fan) want <<= 1;
+        const char* head = getenv("RT_QUEUE_HEADROOM");   // queues this many times larger than the first level needs (deep ray trees)
+        const size_t headroom = std::max<size_t>(1, head ? strtoull(head, nullptr, 10) : 1) * ws.grow;
+        while (want < max_cap && want < npix * (size_t)params.spp * fan * headroom) want <<= 1;
         want = std::min(want, max_cap);
+        max_queue_rays = env_cap >= 4096 ? max_cap : kGrownMaxQueueRays;   // how far run_levels may grow the queues
         if (ws.capacity != 0 && ws.capacity < want) {   // a larger frame than before: drop the queues (nothing is in flight on this stream's workspace after the sync)
             if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
             for (void* p : ws.queues) (void)hipFree(p);
@@ -954,6 +977,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     const size_t first_event = ws.events_used;
     Driver D{scene, params, ws, stream, 0, 0};
     D.may_emit = may_emit;
+    D.max_capacity = max_queue_rays;
     if (!D.may_emit && params.spp == 1 && !d_linear) D.direct = d_rgb8;
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
@@ -987,7 +1011,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
                                ws.counters + kNextBase);
             if (optimistic) {
-                if (D.run_levels(q, (unsigned)n, levels) == 0) continue;
+                const int lr = D.run_levels(q, (unsigned)n, levels);
+                if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] capacity %zu grow %zu -> %s\n", ws.capacity, ws.grow, lr == 0 ? "done" : "overflow");
+                if (lr == 0) continue;
                 // a level outgrew its queue: start the frame over, level by level with batches
                 if (D.err != hipSuccess) break;
                 if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
