@@ -179,8 +179,8 @@ __device__ __forceinline__ void sweep_axis(const int axis, BoxAt&& bb, CountAt&&
 }
 
 // Best split of one axis per span, at [3 * first position + axis]: cost (+inf = none) and the bin below whose upper
-// boundary the span is cut.  One thread per (span, axis); k_sah_pick then takes the cheapest axis, the lowest on equal
-// cost, as the host's loop over the axes does.  Pairs are marked in dec_axis directly.
+// boundary the span is cut.  k_sah_pick then takes the cheapest axis, the lowest on equal cost, as the host's loop over
+// the axes does.  Spans of 3 .. kTinySpan shapes: one thread per (span, axis).
 __global__ void __launch_bounds__(kB) k_sah_choose_short(const double* __restrict__ boxes, const int* __restrict__ perm, const int n,
                                                          const Spans sp, const u64* __restrict__ lo, const u64* __restrict__ hi,
                                                          double* __restrict__ axis_cost, int* __restrict__ axis_bin) {
@@ -188,9 +188,9 @@ __global__ void __launch_bounds__(kB) k_sah_choose_short(const double* __restric
     const int i = j / 3, axis = j - 3 * i;
     if (i >= n || sp.done[i]) return;
     const int s = sp.start[i], e = sp.end[i], m = e - s;
-    if (i != s || m > kShortSpan || m == 2) return;
+    if (i != s || m > kTinySpan || m == 2) return;
     double best_cost = INFINITY;
-    int best_axis = -1, best_bin = -1;
+    int best_bin = -1;
     const double l = decode(lo[3 * (size_t)s + axis]), ext = decode(hi[3 * (size_t)s + axis]) - l;
     if (ext > 0.0 && isfinite(ext) && m <= kTinySpan) {
         // A handful of primitives occupy a handful of bins: instead of filling and sweeping 32 bins in scratch memory,
@@ -219,30 +219,95 @@ __global__ void __launch_bounds__(kB) k_sah_choose_short(const double* __restric
             const double lx = lb[3] - lb[0], ly = lb[4] - lb[1], lz = lb[5] - lb[2];
             const double rx = rb[3] - rb[0], ry = rb[4] - rb[1], rz = rb[5] - rb[2];
             const double cost = (lx * ly + ly * lz + lz * lx) * (double)nl + (rx * ry + ry * rz + rz * rx) * (double)nr;
-            if (cost < best_cost || (cost == best_cost && B < best_bin)) { best_cost = cost; best_axis = axis; best_bin = B; }
+            if (cost < best_cost || (cost == best_cost && B < best_bin)) { best_cost = cost; best_bin = B; }
         }
-    } else if (ext > 0.0 && isfinite(ext)) {
-        double bbox[kBins][6];
-        unsigned count[kBins];
-        const double scale = kBins / ext;
-        for (int b = 0; b < kBins; ++b) {
-            count[b] = 0;
-            for (int k = 0; k < 3; ++k) { bbox[b][k] = INFINITY; bbox[b][3 + k] = -INFINITY; }
-        }
-        for (int k = s; k < e; ++k) {
-            const double* pb = boxes + 6 * (size_t)perm[k];
-            const int b = bin_of(centre_of(pb, axis), l, scale);
-            for (int c = 0; c < 3; ++c) {
-                bbox[b][c] = fmin(bbox[b][c], pb[c]);
-                bbox[b][3 + c] = fmax(bbox[b][3 + c], pb[3 + c]);
-            }
-            ++count[b];
-        }
-        sweep_axis(axis, [&](int b, double* v) { for (int k = 0; k < 6; ++k) v[k] = bbox[b][k]; }, [&](int b) { return count[b]; },
-                   sp.dleft[i], best_cost, best_axis, best_bin);
     }
     axis_cost[3 * (size_t)s + axis] = best_cost;
     axis_bin[3 * (size_t)s + axis] = best_bin;
+}
+
+// Spans of kTinySpan + 1 .. 64 shapes: one WAVE per span (the wave that holds the span's first position takes its spans
+// in turn).  Lane k bins shape k into a table in LDS (64-bit atomics on the order-preserving encodings), lane b then
+// evaluates the split below bin b from the table -- the boxes left and right of it are the unions the host's sweep
+// accumulates, so the cost is the sweep's bit for bit -- and the cheapest (cost, bin) of the lanes is the sweep's choice.
+__global__ void __launch_bounds__(kB) k_sah_choose_mid(const double* __restrict__ boxes, const int* __restrict__ perm, const int n,
+                                                       const Spans sp, const u64* __restrict__ lo, const u64* __restrict__ hi,
+                                                       double* __restrict__ axis_cost, int* __restrict__ axis_bin) {
+    __shared__ u64 s_min[kB / 64][kBins][3], s_max[kB / 64][kBins][3];
+    __shared__ unsigned s_cnt[kB / 64][kBins];
+    const int i = blockIdx.x * kB + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bool leader = false;
+    if (i < n && !sp.done[i]) {
+        const int m = sp.end[i] - sp.start[i];
+        leader = i == sp.start[i] && m > kTinySpan && m <= kShortSpan;
+    }
+    unsigned long long todo = __ballot(leader);
+    const int base = i - lane;
+    while (todo != 0ull) {   // wave-uniform
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int s = base + L;
+        const int e = sp.end[s], m = e - s, depth_left = sp.dleft[s];
+        double pb[6] = {0, 0, 0, 0, 0, 0};
+        if (lane < m) {
+            const double* src = boxes + 6 * (size_t)perm[s + lane];
+            for (int k = 0; k < 6; ++k) pb[k] = src[k];
+        }
+        for (int axis = 0; axis < 3; ++axis) {
+            const double l = decode(lo[3 * (size_t)s + axis]), ext = decode(hi[3 * (size_t)s + axis]) - l;
+            double cost = INFINITY;
+            int bin = -1;
+            if (ext > 0.0 && isfinite(ext)) {
+                if (lane < kBins) {
+                    for (int k = 0; k < 3; ++k) { s_min[w][lane][k] = ~0ull; s_max[w][lane][k] = 0ull; }
+                    s_cnt[w][lane] = 0u;
+                }
+                __threadfence_block();
+                if (lane < m) {
+                    const int b = bin_of((pb[axis] + pb[3 + axis]) * 0.5, l, kBins / ext);
+                    for (int k = 0; k < 3; ++k) {
+                        atomicMin(&s_min[w][b][k], encode(pb[k]));
+                        atomicMax(&s_max[w][b][k], encode(pb[3 + k]));
+                    }
+                    atomicAdd(&s_cnt[w][b], 1u);
+                }
+                __threadfence_block();
+                if (lane + 1 < kBins) {   // split between bin `lane` and the next
+                    double lb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    double rb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    unsigned nl = 0, nr = 0;
+                    for (int b = 0; b < kBins; ++b) {
+                        const unsigned c = s_cnt[w][b];
+                        if (c == 0u) continue;
+                        double* dst = b <= lane ? lb : rb;
+                        for (int k = 0; k < 3; ++k) {
+                            dst[k] = fmin(dst[k], decode(s_min[w][b][k]));
+                            dst[3 + k] = fmax(dst[3 + k], decode(s_max[w][b][k]));
+                        }
+                        if (b <= lane) nl += c; else nr += c;
+                    }
+                    if (nl != 0u && nr != 0u && !(ceil_log2(max(nl, nr)) > depth_left - 1)) {
+                        const double lx = lb[3] - lb[0], ly = lb[4] - lb[1], lz = lb[5] - lb[2];
+                        const double rx = rb[3] - rb[0], ry = rb[4] - rb[1], rz = rb[5] - rb[2];
+                        cost = (lx * ly + ly * lz + lz * lx) * (double)nl + (rx * ry + ry * rz + rz * rx) * (double)nr;
+                        bin = lane;
+                    }
+                }
+                __threadfence_block();   // the table is read before the next axis clears it
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {   // the cheapest split; the lowest bin among equally cheap ones
+                    const double oc = __shfl_xor(cost, off);
+                    const int ob = __shfl_xor(bin, off);
+                    if (ob >= 0 && (bin < 0 || oc < cost || (oc == cost && ob < bin))) { cost = oc; bin = ob; }
+                }
+            }
+            if (lane == 0) {
+                axis_cost[3 * (size_t)s + axis] = bin >= 0 ? cost : INFINITY;
+                axis_bin[3 * (size_t)s + axis] = bin;
+            }
+        }
+    }
 }
 
 // Decision per span, at its first position: axis >= 0 and bin = split below that bin boundary; axis -1 = cut the span in
@@ -497,6 +562,7 @@ hipError_t sah_binary_tree_device(const double* d_boxes, int n, int max_depth, h
         SAH_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), stream));
         hipLaunchKernelGGL(k_sah_centre_bounds, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi);
         hipLaunchKernelGGL(k_sah_choose_short, dim3(g3), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_acost, d_abin);
+        hipLaunchKernelGGL(k_sah_choose_mid, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_acost, d_abin);
         hipLaunchKernelGGL(k_sah_bin_long, dim3(g), dim3(kB), 0, stream, d_boxes, d_perm, n, sp, d_lo, d_hi, d_tmin, d_tmax, d_tcnt);
         hipLaunchKernelGGL(k_sah_choose_long, dim3(g3), dim3(kB), 0, stream, n, sp, d_lo, d_hi, d_tmin, d_tmax, d_tcnt, d_acost, d_abin);
         hipLaunchKernelGGL(k_sah_pick, dim3(g), dim3(kB), 0, stream, n, sp, d_acost, d_abin, d_axis, d_bin);
