@@ -235,3 +235,21 @@ def test_large_degenerate_scene_on_the_default_path(gpu):
     assert out["default"][1]["builder"] == "sah_gpu" and not out["default"][1]["order_on_device"]
     _check_image(out["default"][1], 70_000, check_root_box=False)
     assert np.array_equal(out["default"][0], out["sah"][0])
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "sah_gpu"])
+@pytest.mark.parametrize("name", helpers.CASES)
+def test_every_golden_case_with_device_built_hierarchies(gpu, name, builder):
+    """All deterministic reference images (8-bit max |diff| <= 1) through hierarchies built on the GPU."""
+    desc, params, golden = helpers.load_case(name)
+    rt.set_bvh_builder(builder)
+    try:
+        scene = rt.Scene(desc)
+    finally:
+        rt.set_bvh_builder("default")
+    built = scene.bvh_nodes()["builder"]
+    img = scene.render(params)
+    scene.close()
+    assert built == (builder if desc.desc.n_shapes >= 2 else "sah")
+    mx, nd, _ = helpers.diff_stats(img, golden)
+    assert mx <= 1 and nd <= 0.01 * img.size, (name, builder, mx, nd)
