@@ -578,14 +578,27 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
             unsigned lanes = 0;
             const unsigned first = emit_reserve(E.count, 2u * (unsigned)P.shadow_samples, lanes);   // one atomic per wave and light
             unsigned j = 0;
+            // a point light (radius 0, shading.h:33) has one sample point: direction and distance of its 2 x samples rays
+            // are the same numbers, computed once instead of per ray (a square root and four divisions each)
+            const bool point_light = L.radius == 0.0;
+            D3 d_point = mk(0, 0, 0);
+            double dist_point = 0.0;
+            if (point_light) {
+                const D3 dd = ld3(L.pos) - Pt;
+                dist_point = length(dd);
+                d_point = normalize(dd);
+            }
             for (int pass = 0; pass < 2; ++pass) {
                 const D3 wt = (pass == 0) ? cmul(w, diff * ad_weight) * inv_s : cmul(w, sp) * inv_s;
                 for (int k = 0; k < P.shadow_samples; ++k) {
-                    D3 lp = ld3(L.pos);
-                    if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
-                    D3 d = lp - Pt;
-                    double dist = length(d);
-                    d = normalize(d);
+                    D3 d = d_point;
+                    double dist = dist_point;
+                    if (!point_light) {
+                        const D3 lp = ld3(L.pos) + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
+                        d = lp - Pt;
+                        dist = length(d);
+                        d = normalize(d);
+                    }
                     emit_ray_at(E.out, first + j * lanes, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth, kKindShadow);
                     ++j;
                 }
