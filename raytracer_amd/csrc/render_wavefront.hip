@@ -555,6 +555,12 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     const D3 V = normalize(r.o - Pt);
     D3 ad = cmul(cmul(ld3(M.ambient), ld3(P.ambient_light)), base);
     D3 spec = mk(0, 0, 0);
+    // The queue's tail is one word and every returning atomic on it is a round trip the wave waits for (shading-heavy
+    // frames spend 4/5 of their wave cycles waiting): the slots of the shadow rays of ALL lights of a hit are reserved
+    // with one atomic per wave, and those of all other children with a second one below.
+    unsigned shadow_lanes = 0, shadow_first = 0, shadow_j = 0;
+    if (EMIT && P.shadows && S.n_lights > 0)
+        shadow_first = emit_reserve(E.count, 2u * (unsigned)S.n_lights * (unsigned)P.shadow_samples, shadow_lanes);
     for (int li = 0; li < S.n_lights; ++li) {
         const DLight& L = S.lights[li];
         D3 Lr = ld3(L.pos) - Pt;
@@ -575,9 +581,6 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
             // term (shading.h:154,192), shadow_samples rays each; a ray that reaches the light adds weight/samples.
             const double inv_s = 1.0 / P.shadow_samples;
             const D3 org = Pt + N * P.eps_shadow;
-            unsigned lanes = 0;
-            const unsigned first = emit_reserve(E.count, 2u * (unsigned)P.shadow_samples, lanes);   // one atomic per wave and light
-            unsigned j = 0;
             // a point light (radius 0, shading.h:33) has one sample point: direction and distance of its 2 x samples rays
             // are the same numbers, computed once instead of per ray (a square root and four divisions each)
             const bool point_light = L.radius == 0.0;
@@ -599,8 +602,9 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
                         dist = length(d);
                         d = normalize(d);
                     }
-                    emit_ray_at(E.out, first + j * lanes, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth, kKindShadow);
-                    ++j;
+                    emit_ray_at(E.out, shadow_first + shadow_j * shadow_lanes, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth,
+                                kKindShadow);
+                    ++shadow_j;
                 }
             }
         }
@@ -611,29 +615,38 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     if (!EMIT) return true;
     const int child_depth = q.depth - 1;
     if (child_depth <= 0) return true;  // children would return black without tracing (tracer.h:149)
-    if (has_refl) {  // tracer.h:176-219
-        int samples = P.glossy_samples;
+    // reflection (tracer.h:176-219): samples below the surface are dropped (tracer.h:196-204), so the kept ones are counted
+    // first with a copy of the random stream; then all children of this hit get their slots with one atomic per wave
+    int samples = 0;
+    double rough = 0.0;
+    D3 perfect = mk(0, 0, 0), wr = mk(0, 0, 0), org = mk(0, 0, 0);
+    unsigned mine = 0;
+    if (has_refl) {
+        samples = P.glossy_samples;
         if (q.depth < P.max_bounces) samples = 1;
-        double rough = 1.0 / sqrt(M.shininess);
+        rough = 1.0 / sqrt(M.shininess);
         D3 Vn = normalize(r.d);
-        D3 perfect = normalize(reflect(Vn, h.n));
-        D3 wr = w * refl_weight;
+        perfect = normalize(reflect(Vn, h.n));
+        wr = w * refl_weight;
         if (M.is_metal) wr = cmul(wr, ld3(M.diffuse));
-        D3 org = h.p + h.n * eps;
+        org = h.p + h.n * eps;
         if (samples > 0) {
             wr = wr * (1.0 / samples);
-            // samples below the surface are dropped (tracer.h:196-204): count the kept ones first with a copy of the
-            // random stream, reserve their slots with one atomic per wave, then draw the same samples again and queue them
-            unsigned kept = 0;
-            {
-                Rng dry = rng;
-                for (int k = 0; k < samples; ++k) {
-                    D3 off = dry.in_unit_sphere() * rough;
-                    D3 target = normalize(perfect + off);
-                    if (dot(target, h.n) > 0) { ++kept; (void)dry.next(); }
-                }
+            Rng dry = rng;
+            for (int k = 0; k < samples; ++k) {
+                D3 off = dry.in_unit_sphere() * rough;
+                D3 target = normalize(perfect + off);
+                if (dot(target, h.n) > 0) { ++mine; (void)dry.next(); }
             }
-            unsigned slot = emit_reserve_counted(E.count, kept);
+        } else {
+            mine = 1;
+        }
+    }
+    if (tir_mirror) ++mine;
+    if (do_refract) ++mine;
+    unsigned slot = emit_reserve_counted(E.count, mine);
+    if (has_refl) {
+        if (samples > 0) {
             for (int k = 0; k < samples; ++k) {
                 D3 off = rng.in_unit_sphere() * rough;
                 D3 target = normalize(perfect + off);
@@ -641,15 +654,15 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
                     emit_ray_at(E.out, slot++, E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
             }
         } else {
-            emit_ray(E.out, E.count, E.cap, E.overflow, org, perfect, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+            emit_ray_at(E.out, slot++, E.cap, E.overflow, org, perfect, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
         }
     }
     if (tir_mirror)  // tracer.h:258-264 (not tinted for metals)
-        emit_ray(E.out, E.count, E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time, 100000.0,
-                 rng.next(), q.pixel, child_depth, kKindRadiance);
+        emit_ray_at(E.out, slot++, E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time, 100000.0,
+                    rng.next(), q.pixel, child_depth, kKindRadiance);
     if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
-        emit_ray(E.out, E.count, E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time, 100000.0,
-                 rng.next(), q.pixel, child_depth, kKindRadiance);
+        emit_ray_at(E.out, slot++, E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time, 100000.0,
+                    rng.next(), q.pixel, child_depth, kKindRadiance);
     return true;
 }
 
