@@ -559,8 +559,10 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     // frames spend 4/5 of their wave cycles waiting): the slots of the shadow rays of ALL lights of a hit are reserved
     // with one atomic per wave, and those of all other children with a second one below.
     unsigned shadow_lanes = 0, shadow_first = 0, shadow_j = 0;
-    if (EMIT && P.shadows && S.n_lights > 0)
-        shadow_first = emit_reserve(E.count, 2u * (unsigned)S.n_lights * (unsigned)P.shadow_samples, shadow_lanes);
+    if (EMIT && P.shadows && S.n_lights > 0) {
+        const unsigned per_hit = 2u * (unsigned)S.n_lights * (unsigned)P.shadow_samples;
+        shadow_first = emit_reserve(E.count, per_hit, shadow_lanes);
+    }
     for (int li = 0; li < S.n_lights; ++li) {
         const DLight& L = S.lights[li];
         D3 Lr = ld3(L.pos) - Pt;
