@@ -37,6 +37,7 @@ def main():
         sf, params = load(name, w, h, spp, rng)
         scene = rt.Scene(sf)
         scene.render(params)   # warm-up (allocates queues)
+        scene.render(params)   # second warm-up: the first frame on grown queues can stall for seconds (end)
         t0 = time.perf_counter()
         img, st = scene.render(params, stats=True)
         wall = (time.perf_counter() - t0) * 1e3
