@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--gather-per-frame", action="store_true",
+                    help="several GPUs: one gather per frame instead of one per --frames-in-flight frames")
     ap.add_argument("--frames-in-flight", type=int, default=8,
                     help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,11 +153,61 @@ def main():
     # every rank.
     F = max(1, args.frames_in_flight)
     streams = [torch.cuda.Stream(dev) for _ in range(F)]
-    gathers = [FrameGather(W, H, args.tile_rows, dev) for _ in range(F)]   # slice, gather buffers, de-interleave index (rank 0)
     counters = torch.zeros(8, dtype=torch.int64, device=dev)   # RT_N_COUNTERS
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Several ranks: a rank's share of a frame is small (0.78 MB and ~0.12 ms of rendering at 8 ranks), so one collective per
+    # frame would be bound by its launch and host cost.  The slices of F consecutive steps travel in ONE gather instead
+    # (FrameGather(frames=F)), issued on a stream of its own once the F renders have finished; two such sets alternate, so
+    # the next F steps render while the gather of the previous F is in flight, and a set is written again only after its
+    # gather has read it (events both ways).  --gather-per-frame keeps one gather per step on the step's stream.
+    batched = world > 1 and not args.gather_per_frame
+    if batched:
+        sets = [FrameGather(W, H, args.tile_rows, dev, frames=F) for _ in range(2)]
+        gather_stream = torch.cuda.Stream(dev)
+        ready = [[torch.cuda.Event() for _ in range(F)] for _ in range(2)]
+        done = [None, None]
+        issued = [0]   # steps issued so far: step j writes slices[j % F] of set (j // F) % 2
+    else:
+        gathers = [FrameGather(W, H, args.tile_rows, dev) for _ in range(F)]   # slice, gather buffers, de-interleave index (rank 0)
+
+    def flush():
+        """Batched gather of the steps issued since the last one (a full set, or a partial one, which is then closed).
+        Collective: every rank calls it at the same steps.  Returns the set gathered last."""
+        j = issued[0]
+        pending = j - flush.upto
+        if pending == 0:
+            return flush.last
+        s = ((j - 1) // F) % 2
+        for b in range(pending):
+            gather_stream.wait_event(ready[s][b])
+        with torch.cuda.stream(gather_stream):
+            sets[s].run()   # RCCL gather of [F, max_rows, W, 3] per rank to rank 0 + one de-interleave of the F frames
+            done[s] = torch.cuda.Event()
+            done[s].record(gather_stream)
+        issued[0] = flush.upto = (j + F - 1) // F * F   # the next step starts the other set
+        flush.last = sets[s]
+        return flush.last
+    flush.upto, flush.last = 0, None
 
     def step(i=None, collect=False, slot=None):
+        if batched:
+            j = issued[0]
+            b, s = j % F, (j // F) % 2
+            stream = streams[b if slot is None else slot]
+            with torch.cuda.stream(stream):
+                if done[s] is not None:
+                    stream.wait_event(done[s])   # the set's previous gather has read the slices
+                if i is not None:
+                    ev[i][0].record(stream)
+                scene.render_device(params, sets[s].slices[b].data_ptr(), counters.data_ptr() if collect else None,
+                                    collect_counters=collect, stream=stream.cuda_stream)
+                if i is not None:
+                    ev[i][1].record(stream)
+                ready[s][b].record(stream)
+            issued[0] = j + 1
+            if b == F - 1:
+                flush()
+            return
         if slot is None:
             slot = 0 if i is None else i % F
         stream, fg = streams[slot], gathers[slot]
@@ -171,6 +223,8 @@ def main():
     # one untimed counting pass: rays, box tests, primitive tests per frame of this rank
     counters.zero_()
     step(collect=True)
+    if batched:
+        flush()
     torch.cuda.synchronize(dev)
     c = counters.cpu().numpy().astype(np.int64)
     if world > 1:
@@ -185,6 +239,8 @@ def main():
     for w in range(args.warmup):
         for slot in range(F):   # every slot allocates its queues and RCCL warms up
             step(slot=slot)
+        if batched:
+            flush()
     torch.cuda.synchronize(dev)
     for s in streams:
         scene.traverse_time(s.cuda_stream)   # drop the warm-up launches from the kernel timing
@@ -194,6 +250,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if batched:
+        flush()   # the last, possibly partial, set
     t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (launches + collectives), before waiting for the GPU
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -216,6 +274,8 @@ def main():
     if F > 1:
         for i in range(max(3, min(args.steps, 10))):
             step(slot=0)
+            if batched:
+                flush()
             torch.cuda.synchronize(dev)
         ms, launches_alone = scene.traverse_time(streams[0].cuda_stream)
         traverse_ms = ms / max(1, launches_alone)
@@ -227,6 +287,7 @@ def main():
     frame_ok = None
     if world > 1:
         step(slot=0)
+        last = flush() if batched else gathers[0]
         torch.cuda.synchronize(dev)
         if rank == 0:
             whole = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
@@ -234,7 +295,7 @@ def main():
             p1.part_count, p1.part_index = 1, 0
             scene.render_device(p1, whole.data_ptr(), stream=streams[0].cuda_stream)
             torch.cuda.synchronize(dev)
-            frame_ok = bool(torch.equal(whole, gathers[0].frame))
+            frame_ok = bool(torch.equal(whole, last.frame))
         dist.barrier()
 
     if rank == 0:
@@ -263,7 +324,7 @@ def main():
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
-                       "frames_in_flight": F, "scene_create_ms": round(t_create * 1e3, 1),
+                       "frames_in_flight": F, "frames_per_gather": (F if batched else 1) if world > 1 else None, "scene_create_ms": round(t_create * 1e3, 1),
                        "gathered_frame_equals_whole_frame": frame_ok},
             "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

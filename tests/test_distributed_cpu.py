@@ -1,6 +1,7 @@
 """world_size-2 and -3 gloo runs (CPU) of the multi-GPU frame assembly used by bench.py: every rank fills the slice it
 would have rendered (rows of a known frame, interleaved row tiles), the slices are gathered to rank 0 and
-de-interleaved; rank 0 must end up with the known frame.  The GPU render itself is covered by the -m gpu tests
+de-interleaved; rank 0 must end up with the known frame (and, with several frames per gather as bench.py sends them, with
+every frame of the batch).  The GPU render itself is covered by the -m gpu tests
 (test_row_tile_partition_reassembles)."""
 import os
 import socket
@@ -21,18 +22,23 @@ WORKER = textwrap.dedent("""
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     W, H, tile = 40, int(os.environ["RT_TEST_H"]), int(os.environ["RT_TEST_TILE"])
+    B = int(os.environ.get("RT_TEST_FRAMES", "1"))
     rng = np.random.default_rng(5)
-    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)          # same on every rank
-    fg = FrameGather(W, H, tile, torch.device("cpu"))
+    frames = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)      # same on every rank
+    frame = frames[0]
+    fg = FrameGather(W, H, tile, torch.device("cpu"), frames=B) if B > 1 else FrameGather(W, H, tile, torch.device("cpu"))
     rows = rt.part_rows(H, tile, rank, world)
     # what rt_render_device writes: this rank's tiles, compacted in tile order
     n_tiles = (H + tile - 1) // tile
-    mine = np.concatenate([frame[t * tile:min(H, (t + 1) * tile)] for t in range(rank, n_tiles, world)] or [frame[:0]])
-    assert mine.shape[0] == rows
-    fg.slice[:rows] = torch.from_numpy(mine)
+    for b in range(B):
+        mine = np.concatenate([frames[b, t * tile:min(H, (t + 1) * tile)] for t in range(rank, n_tiles, world)] or [frame[:0]])
+        assert mine.shape[0] == rows
+        fg.slices[b, :rows] = torch.from_numpy(mine)
+    assert fg.slice.data_ptr() == fg.slices.data_ptr()
     out = fg.run()
     if rank == 0:
-        assert out is not None and np.array_equal(out.numpy(), frame), "frame mismatch"
+        assert out is not None and np.array_equal(out.numpy(), frame if B == 1 else frames), "frame mismatch"
+        assert np.array_equal(fg.frame.numpy(), frame)
         # the C-ABI scatter helper must agree with the index-select path
         chk = np.zeros_like(frame)
         for k in range(world):
@@ -54,11 +60,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,height,tile", [(2, 1080 // 8, 8), (3, 70, 16), (2, 9, 4)])
-def test_gather_and_deinterleave(tmp_path, world, height, tile):
+@pytest.mark.parametrize("world,height,tile,frames", [(2, 1080 // 8, 8, 1), (3, 70, 16, 1), (2, 9, 4, 1), (2, 70, 8, 4), (3, 33, 4, 8)])
+def test_gather_and_deinterleave(tmp_path, world, height, tile, frames):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, RT_TEST_H=str(height), RT_TEST_TILE=str(tile), OMP_NUM_THREADS="1")
+    env = dict(os.environ, RT_TEST_H=str(height), RT_TEST_TILE=str(tile), RT_TEST_FRAMES=str(frames), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
