@@ -40,7 +40,7 @@ import torch.distributed as dist  # noqa: E402
 
 import raytracer_amd as rt  # noqa: E402
 from raytracer_amd import workloads  # noqa: E402
-from raytracer_amd.distributed import FrameGather  # noqa: E402
+from raytracer_amd.distributed import FrameGather, init_comm  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NODE_BYTES = 64           # one DNode4: four quantised child boxes + child references (device_types.h)
@@ -120,12 +120,29 @@ def reference_check(threads, n_spheres=100_000):
             "images_identical": bool(np.array_equal(ref_img, port_img))}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (torch.distributed.run, one process per GPU)
+    BEFORE anything in this process touches a GPU, and pass on their exit code.  Never a single-rank result for N > 1."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:   # counting devices does not initialise the GPU
+            raise SystemExit("bench.py: --gpus %d asked for, %d visible: not measured" % (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU
@@ -137,6 +154,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
     rt.init(local_rank)
+    if world > 1 and args.backend == "nccl":
+        init_comm(dev)   # the library's own RCCL communicator: slices travel by rt_gather_frames (comm.hip)
 
     cfg = workloads.default_config()
     scene_desc = workloads.bvh_stress_scene(args.spheres, args.width, args.height)
@@ -320,7 +339,7 @@ def main():
             "config": {"workload": "C2: %d random ellipsoids (default_rng(12345)), %dx%d, Whitted 1 spp, default flags, BVH on"
                                    % (args.spheres, W, H),
                        "partition": "interleaved row tiles of %d rows over %d GPU(s), u8 slices gathered to rank 0 (%s)"
-                                    % (args.tile_rows, world, "RCCL" if args.backend == "nccl" else args.backend + " REHEARSAL, not a measurement"),
+                                    % (args.tile_rows, world, "rt_gather_frames: RCCL send/recv + k_deinterleave" if args.backend == "nccl" else args.backend + " REHEARSAL, not a measurement"),
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
@@ -343,6 +362,7 @@ def main():
     scene.close()
     if world > 1:
         dist.barrier()
+        rt.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -279,13 +279,23 @@ int rt_bvh_order_device(const RtSceneDesc* desc, int32_t* order_out, double* dev
  * owned by part_index are written; the rest of the buffer is left untouched.  stats may be NULL. */
 int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats);
 
-/* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t, NULL = the library's
- * stream): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice
+/* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t with HIP's own meaning: NULL is
+ * the null stream, which is also PyTorch's default stream, so whatever the caller enqueues there afterwards is ordered
+ * behind the render): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice
  * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to RT_N_COUNTERS (8) uint64 (rays, box tests,
  * primitive tests, nanoseconds spent in the traversal kernel, hierarchy nodes fetched, most nodes fetched by one ray, most scheduler iterations of one wave, reserved) that the
  * kernel adds into (the two maxima are max-combined); collect_counters!=0 additionally counts node/primitive tests. */
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);
+
+/* Ray queues of the wavefront schedule are kept per HIP stream for the life of the process, not per scene: a service that
+ * opens and closes scenes keeps them.  rt_reserve allocates (or grows to) n_queues queues of rays_per_queue rays (144 bytes
+ * per ray) for `hip_stream` and touches every page, so that the first frame rendered on that stream pays neither the
+ * allocation nor the first touch (seconds, for tens of GB); rt_render_device otherwise sizes the queues by the first
+ * frame and grows them when a larger one comes.  rt_release_workspaces waits for the device and frees all of them.
+ * No counterpart in the reference (host memory, Code/main.cpp:242). */
+int rt_reserve(void* hip_stream, uint64_t rays_per_queue, int n_queues);
+int rt_release_workspaces(void);
 
 /* Linear radiance: the per-pixel average over the samples BEFORE tone mapping and 8-bit truncation (the `avg_colour`
  * of main.cpp:306-308), 3 doubles per pixel, row-major, top row first.  For float (PFM) output and for progressive /
@@ -307,6 +317,41 @@ int rt_part_rows(int height, int tile_rows, int part_index, int part_count);
 /* Scatter a compact part slice (as written by rt_render_device) into a full row-major frame (host memory). */
 int rt_part_scatter(const uint8_t* slice, uint8_t* frame, int width, int height, int tile_rows, int part_index,
                     int part_count);
+
+/* ---- several GPUs: one process per GPU, slices gathered over RCCL / xGMI ------------------------
+ * The reference shares one `Image` between its OpenMP threads (main.cpp:242,279-320: every thread's setPixel lands in the
+ * same buffer).  With one process per GPU that buffer is assembled on rank 0: every rank renders its interleaved row
+ * tiles into a compact slice (rt_render_device with part_index = rank, part_count = world), the slices travel to rank 0
+ * as one grouped ncclSend / ncclRecv per rank (RCCL, bound at run time: single-GPU users never load it), and a HIP
+ * kernel puts the rows where Image::m_pixel_data has them (Image.h:46-47).  No other exchange exists on the path.
+ *
+ * Bootstrap: rank 0 calls rt_comm_unique_id and hands the RT_COMM_ID_BYTES to the other ranks by whatever the launcher
+ * offers (torch.distributed broadcast, a file, MPI); every rank then calls rt_comm_init after rt_init.  One communicator
+ * per process.  rt_comm_rank / rt_comm_world return 0 / 1 without one. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void* id_out);
+int rt_comm_init(int rank, int world, const void* id);
+int rt_comm_rank(void);
+int rt_comm_world(void);
+int rt_comm_destroy(void);
+/* Collective (every rank, same arguments except the pointers), asynchronous on `hip_stream`.  d_slices: this rank's
+ * slices of `frames` consecutive frames, device memory, frames x max_rows x width x 3 bytes, where max_rows is the
+ * largest rt_part_rows over the ranks (frame b at offset b * max_rows * width * 3: a rank with fewer rows leaves the tail
+ * of each slot unused) -- several frames travel in one message, because a rank's share of one frame is small (0.78 MB of
+ * a 1080p frame at 8 ranks) and the exchange is bound by its launch cost.  d_frames (rank 0 only, else ignored):
+ * frames x height x width x 3 bytes, row-major, top row first.  Without a communicator (one GPU) it only reorders.
+ * Rank 0 keeps a staging buffer of world x frames x max_rows x width x 3 bytes, grown on demand, until rt_comm_destroy. */
+int rt_gather_frames(const void* d_slices, int frames, int width, int height, int tile_rows, void* d_frames, void* hip_stream);
+/* rt_render for an N-GPU job -- the drop-in for the body of render_scene_func (main.cpp:229-359) when the frame is shared
+ * by several GPUs.  Collective: every rank calls it with the same scene and params (part_index / part_count are set from
+ * the communicator); each rank renders its tiles, the slices are gathered, and rank 0 gets the whole frame in rgb8_out
+ * (H*W*3 bytes; other ranks may pass NULL).  stats (may be NULL) describe this rank's share.  Without a communicator it
+ * is rt_render. */
+int rt_render_gathered(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats);
+/* The reordering kernel alone: d_gathered = [world][frames][max_rows][width*3] as rt_gather_frames receives it; d_own
+ * (may be NULL) replaces rank 0's block with [frames][max_rows][width*3] elsewhere.  The device-side rt_part_scatter. */
+int rt_deinterleave_device(const void* d_own, const void* d_gathered, void* d_frames, int frames, int width, int height, int tile_rows,
+                           int world, void* hip_stream);
 
 /* ---- host side kept from the reference: config.json, scene files, images ---------------------- */
 

@@ -118,7 +118,9 @@ ABI_SYMBOLS = [
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
     "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
-    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device",
+    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_reserve",
+    "rt_release_workspaces", "rt_comm_unique_id", "rt_comm_init", "rt_comm_rank", "rt_comm_world", "rt_comm_destroy",
+    "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered",
 ]
 
 
@@ -166,6 +168,12 @@ def _load():
         "rt_bvh_order_device": (i32, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
+        "rt_reserve": (i32, [vp, C.c_uint64, i32]), "rt_release_workspaces": (i32, []),
+        "rt_comm_unique_id": (i32, [vp]), "rt_comm_init": (i32, [i32, i32, vp]), "rt_comm_rank": (i32, []),
+        "rt_comm_world": (i32, []), "rt_comm_destroy": (i32, []),
+        "rt_gather_frames": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+        "rt_render_gathered": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
+        "rt_deinterleave_device": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rt_part_rows": (i32, [i32, i32, i32, i32]),
         "rt_part_scatter": (i32, [vp, vp, i32, i32, i32, i32, i32]),
         "rt_config_load": (i32, [cp, C.POINTER(vp)]), "rt_config_parse": (i32, [cp, C.POINTER(vp)]),
@@ -207,6 +215,52 @@ def init(device_id=-1):
 
 def shutdown():
     lib.rt_shutdown()
+
+
+def reserve(stream, rays_per_queue, n_queues=2):
+    """Allocate and first-touch the ray queues of `stream` ahead of the first frame (see rt_reserve)."""
+    _check(lib.rt_reserve(stream, int(rays_per_queue), int(n_queues)))
+
+
+def release_workspaces():
+    _check(lib.rt_release_workspaces())
+
+
+# ---------------------------------------------------------------------------------------- several GPUs (RCCL inside the library)
+RT_COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """Rank 0: the bytes every rank passes to comm_init (hand them over with the launcher's own means)."""
+    buf = C.create_string_buffer(RT_COMM_ID_BYTES)
+    _check(lib.rt_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(rank, world, unique_id):
+    _check(lib.rt_comm_init(int(rank), int(world), C.create_string_buffer(bytes(unique_id), RT_COMM_ID_BYTES)))
+
+
+def comm_rank():
+    return lib.rt_comm_rank()
+
+
+def comm_world():
+    return lib.rt_comm_world()
+
+
+def comm_destroy():
+    _check(lib.rt_comm_destroy())
+
+
+def gather_frames(d_slices_ptr, frames, width, height, tile_rows, d_frames_ptr, stream=None):
+    """Collective: slices of `frames` frames to rank 0 over RCCL + de-interleave kernel (see rt_gather_frames)."""
+    _check(lib.rt_gather_frames(d_slices_ptr, int(frames), int(width), int(height), int(tile_rows), d_frames_ptr, stream))
+
+
+def deinterleave_device(d_own_ptr, d_gathered_ptr, d_frames_ptr, frames, width, height, tile_rows, world, stream=None):
+    _check(lib.rt_deinterleave_device(d_own_ptr, d_gathered_ptr, d_frames_ptr, int(frames), int(width), int(height), int(tile_rows),
+                                      int(world), stream))
 
 
 BVH_BUILDERS = {"default": -1, "sah": 0, "lbvh": 1, "median": 2, "sah_gpu": 3}   # RT_BVH_* of rt_mi355x.h
@@ -456,6 +510,15 @@ class Scene:
         _check(lib.rt_render(self._h, C.byref(params), img.ctypes.data, C.byref(st) if stats else None))
         return (img, st) if stats else img
 
+    def render_gathered(self, params, stats=False):
+        """Collective over the library's communicator: every rank renders its tiles, rank 0 returns the whole frame (the
+        other ranks None).  See rt_render_gathered."""
+        root = comm_rank() == 0
+        img = np.zeros((self.height, self.width, 3), dtype=np.uint8) if root else None
+        st = RtStats()
+        _check(lib.rt_render_gathered(self._h, C.byref(params), img.ctypes.data if root else None, C.byref(st) if stats else None))
+        return (img, st) if stats else img
+
     def render_linear(self, params):
         """One frame of linear radiance (before tone mapping): float64 [H, W, 3] (see rt_render_linear)."""
         img = np.zeros((self.height, self.width, 3), dtype=np.float64)
@@ -466,7 +529,8 @@ class Scene:
         _check(lib.rt_render_linear_device(self._h, C.byref(params), d_rgb_f64_ptr, stream))
 
     def render_device(self, params, d_rgb8_ptr, d_counters_ptr=None, collect_counters=False, stream=None):
-        """Asynchronous render of this part's rows into device memory (see rt_render_device)."""
+        """Asynchronous render of this part's rows into device memory (see rt_render_device).  stream: a hipStream_t value
+        (torch: `stream.cuda_stream`); None is the null stream, i.e. torch's default stream."""
         _check(lib.rt_render_device(self._h, C.byref(params), d_rgb8_ptr, d_counters_ptr, int(collect_counters), stream))
 
     def traverse_time(self, stream=None):

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
+#include "api_internal.h"
 #include "device_types.h"
 #include "bvh_build.h"
 #include "host_bvh.h"
@@ -50,6 +51,21 @@ struct DeviceState {
     uint64_t* d_counters = nullptr;  // RT_N_COUNTERS x u64
 };
 DeviceState g_dev;
+
+// Workspaces of the wavefront schedule (ray queues, accumulators, counters): one per HIP stream, process-wide, so that
+// they outlive the scenes rendered through them -- a service that opens and closes scenes keeps its queues, and the
+// first frame of a new scene does not pay for allocating and first touching gigabytes (rt_reserve does, when asked).
+// Freed by rt_release_workspaces / rt_shutdown.  The mutex guards the map, not the workspaces: one render at a time per stream.
+std::map<hipStream_t, rt::WavefrontWorkspace> g_wf;
+std::mutex g_wf_mutex;
+unsigned long long g_scene_serial = 0;
+
+rt::WavefrontWorkspace* workspace_of(hipStream_t st, bool create) {
+    std::lock_guard<std::mutex> lock(g_wf_mutex);
+    if (create) return &g_wf[st];   // std::map: references stay valid when other streams are added
+    auto it = g_wf.find(st);
+    return it == g_wf.end() ? nullptr : &it->second;
+}
 
 // std::vector without the zero fill of resize(): the big per-primitive arrays are written in full right after.
 template <typename T>
@@ -87,8 +103,6 @@ struct rt_scene_s {
     DScene d{};                       // device view (pointers are device pointers)
     std::vector<void*> allocations;   // everything to hipFree
     uint8_t* d_frame = nullptr;       // scratch framebuffer for rt_render
-    std::map<hipStream_t, WavefrontWorkspace> wf;   // queues / accumulators of the wavefront schedule, one set per stream
-    std::mutex wf_mutex;              // guards the map (not the workspaces: one render at a time per stream)
     size_t d_frame_bytes = 0;
     bool on_device = false;
 };
@@ -98,6 +112,12 @@ struct rt_config_s {
 struct rt_scene_file_s {
     std::unique_ptr<SceneFile> scene;
 };
+
+namespace rt {
+int api_fail(int code, const std::string& msg) { return fail(code, msg); }
+bool api_ready() { return g_dev.ready; }
+int api_device() { return g_dev.device; }
+}  // namespace rt
 
 static int validate_desc(const RtSceneDesc* d) {
     if (!d) return fail(RT_ERR_INVALID, "scene description is NULL");
@@ -305,9 +325,30 @@ int rt_init(int device_id) {
     return RT_OK;
 }
 
+int rt_release_workspaces(void) {
+    if (!g_dev.ready) return RT_OK;
+    HIP_TRY(hipSetDevice(g_dev.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_wf_mutex);
+    for (auto& kv : g_wf) wavefront_workspace_free(kv.second);
+    g_wf.clear();
+    return RT_OK;
+}
+
+int rt_reserve(void* hip_stream, uint64_t rays_per_queue, int n_queues) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (rays_per_queue == 0 || rays_per_queue > (uint64_t(1) << 31) || n_queues < 1 || n_queues > 64)
+        return fail(RT_ERR_INVALID, "rt_reserve: rays_per_queue must be 1 .. 2^31 and n_queues 1 .. 64");
+    HIP_TRY(hipSetDevice(g_dev.device));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = wavefront_reserve(*workspace_of(st, true), static_cast<size_t>(rays_per_queue), n_queues, st);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RT_ERR_LIMIT : RT_ERR_DEVICE, std::string("rt_reserve: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
 void rt_shutdown(void) {
     if (!g_dev.ready) return;
-    (void)hipSetDevice(g_dev.device);
+    (void)rt_release_workspaces();
     if (g_dev.stream) (void)hipStreamDestroy(g_dev.stream);
     if (g_dev.ev0) (void)hipEventDestroy(g_dev.ev0);
     if (g_dev.ev1) (void)hipEventDestroy(g_dev.ev1);
@@ -499,6 +540,10 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     for (int a = 0; a < 3; ++a) { d.root_lo[a] = b32.root_lo[a]; d.root_hi[a] = b32.root_hi[a]; }
     d.shutter_time = desc->shutter_time;
     d.cam = h.cam;
+    {
+        std::lock_guard<std::mutex> lock(g_wf_mutex);
+        d.serial = ++g_scene_serial;
+    }
     sc->on_device = true;
     *out = sc.release();
     return RT_OK;
@@ -510,7 +555,6 @@ void rt_scene_destroy(rt_scene_t scene) {
         (void)hipSetDevice(g_dev.device);
         for (void* p : scene->allocations) (void)hipFree(p);
         if (scene->d_frame) (void)hipFree(scene->d_frame);
-        for (auto& kv : scene->wf) wavefront_workspace_free(kv.second);
     }
     delete scene;
 }
@@ -630,6 +674,8 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     return RT_OK;
 }
 
+// hip_stream is a hipStream_t with HIP's own meaning: NULL is the null stream (which is torch's default stream), so work the
+// caller enqueues on that stream afterwards is ordered behind the render.
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters, int collect_counters, void* hip_stream) {
     if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
     if (!d_rgb8) return fail(RT_ERR_INVALID, "d_rgb8 is NULL");
@@ -638,19 +684,13 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     if (rc) return rc;
     if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
     if (dp.part_rows == 0) return RT_OK;
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
     hipError_t e;
     if (params->schedule == RT_SCHEDULE_MEGAKERNEL)
         e = launch_render_mega(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
     else
-    {
-        WavefrontWorkspace* ws;
-        {
-            std::lock_guard<std::mutex> lock(scene->wf_mutex);
-            ws = &scene->wf[st];   // std::map: references stay valid when other streams are added
-        }
-        e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st, *ws);
-    }
+        e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
+                                    *workspace_of(st, true));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }
@@ -664,13 +704,8 @@ int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void
     if (params->schedule != RT_SCHEDULE_WAVEFRONT) return fail(RT_ERR_INVALID, "linear output needs the wavefront schedule");
     if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
     if (dp.part_rows == 0) return RT_OK;
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
-    WavefrontWorkspace* ws;
-    {
-        std::lock_guard<std::mutex> lock(scene->wf_mutex);
-        ws = &scene->wf[st];
-    }
-    hipError_t e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, *ws, static_cast<double*>(d_rgb_f64));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, *workspace_of(st, true), static_cast<double*>(d_rgb_f64));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }
@@ -695,13 +730,8 @@ int rt_render_linear(rt_scene_t scene, const RtRenderParams* params, double* rgb
 
 int rt_traverse_time(rt_scene_t scene, void* hip_stream, double* ms_out, uint64_t* launches_out) {
     if (!scene || !ms_out || !launches_out) return fail(RT_ERR_INVALID, "NULL argument");
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : g_dev.stream;
-    WavefrontWorkspace* ws = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(scene->wf_mutex);
-        auto it = scene->wf.find(st);
-        if (it != scene->wf.end()) ws = &it->second;
-    }
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    WavefrontWorkspace* ws = workspace_of(st, false);
     *ms_out = 0.0;
     *launches_out = 0;
     if (!ws) return RT_OK;
@@ -745,6 +775,62 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
         if (rc) return rc;
     }
     if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_dev.ev0, g_dev.ev1));
+        stats->rays = counters[0];
+        stats->nodes_visited = counters[1];
+        stats->prims_tested = counters[2];
+        stats->nodes_fetched = counters[4];
+        stats->kernel_ms = ms;
+        stats->traverse_ms = static_cast<double>(counters[3]) * 1e-6;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+// rt_render for every rank of the communicator (collective): each rank renders its interleaved row tiles, the slices are
+// gathered over RCCL and rank 0 receives the assembled frame in host memory.
+int rt_render_gathered(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!scene || !params) return fail(RT_ERR_INVALID, "NULL argument");
+    const int world = rt_comm_world(), rank = rt_comm_rank();
+    const char* lb = std::getenv("RT_COMM_LOOPBACK");
+    if (world == 1 && !(lb && lb[0] == '1')) {
+        RtRenderParams q = *params;
+        q.part_index = 0; q.part_count = 1;
+        return rt_render(scene, &q, rgb8_out, stats);
+    }
+    if (rank == 0 && !rgb8_out) return fail(RT_ERR_INVALID, "rank 0 needs rgb8_out");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(g_dev.device));
+    RtRenderParams q = *params;
+    q.part_index = rank; q.part_count = world;
+    const int tile = q.tile_rows > 0 ? q.tile_rows : 8;
+    q.tile_rows = tile;
+    int max_rows = 0;
+    for (int k = 0; k < world; ++k) max_rows = std::max(max_rows, rt_part_rows(scene->height, tile, k, world));
+    const size_t slice_bytes = static_cast<size_t>(max_rows) * scene->width * 3;
+    const size_t frame_bytes = static_cast<size_t>(scene->height) * scene->width * 3;
+    const size_t bytes = slice_bytes + (rank == 0 ? frame_bytes : 0);   // [slice][assembled frame]
+    if (scene->d_frame_bytes < bytes) {
+        if (scene->d_frame) (void)hipFree(scene->d_frame);
+        scene->d_frame = nullptr;
+        scene->d_frame_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame), bytes));
+        scene->d_frame_bytes = bytes;
+    }
+    HIP_TRY(hipMemsetAsync(g_dev.d_counters, 0, RT_N_COUNTERS * sizeof(uint64_t), g_dev.stream));
+    HIP_TRY(hipEventRecord(g_dev.ev0, g_dev.stream));
+    int rc = rt_render_device(scene, &q, scene->d_frame, g_dev.d_counters, stats != nullptr, g_dev.stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g_dev.ev1, g_dev.stream));
+    rc = rt_gather_frames(scene->d_frame, 1, scene->width, scene->height, tile, rank == 0 ? scene->d_frame + slice_bytes : nullptr, g_dev.stream);
+    if (rc) return rc;
+    if (rank == 0) HIP_TRY(hipMemcpyAsync(rgb8_out, scene->d_frame + slice_bytes, frame_bytes, hipMemcpyDeviceToHost, g_dev.stream));
+    uint64_t counters[RT_N_COUNTERS] = {};
+    HIP_TRY(hipMemcpyAsync(counters, g_dev.d_counters, sizeof(counters), hipMemcpyDeviceToHost, g_dev.stream));
+    HIP_TRY(hipStreamSynchronize(g_dev.stream));
+    if (stats) {   // this rank's share
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g_dev.ev0, g_dev.ev1));
         stats->rays = counters[0];

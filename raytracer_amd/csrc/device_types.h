@@ -138,6 +138,7 @@ struct DScene {
     int32_t transparent_materials;  // 1 when some material transmits (shadow rays then need their CLOSEST occluder)
     double shutter_time;
     DCamera cam;
+    uint64_t serial;                // identifies the scene inside this process (host bookkeeping only)
 };
 
 enum : int32_t {

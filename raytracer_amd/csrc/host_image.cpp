@@ -1,13 +1,18 @@
 #include "host_image.h"
 
+#include <spawn.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+
+extern char** environ;
 
 namespace rt {
 
@@ -111,6 +116,28 @@ bool read_pfm(const std::string& path, ImageF& out, std::string* why) {
     return true;
 }
 
+// Runs `interpreter -c <fixed script> <src> <dst>` without a shell (the reference splices the texture path into a
+// `python3 -c "..."` command line for std::system, scene.cpp:46-66: a file name with a quote, a backtick or $(...) in a scene
+// file would run as shell or Python code).  The paths travel as sys.argv, never as program text.
+static bool convert_with_pil(const char* interpreter, const std::string& src, const std::string& dst) {
+    static const char* kScript =
+        "import sys\n"
+        "try:\n"
+        "    from PIL import Image\n"
+        "    Image.open(sys.argv[1]).convert('RGB').save(sys.argv[2], format='PPM')\n"
+        "except Exception as e:\n"
+        "    print(e)\n"
+        "    sys.exit(1)\n";
+    char* const argv[] = {const_cast<char*>(interpreter), const_cast<char*>("-c"), const_cast<char*>(kScript),
+                          const_cast<char*>(src.c_str()), const_cast<char*>(dst.c_str()), nullptr};
+    pid_t pid = 0;
+    if (posix_spawnp(&pid, interpreter, nullptr, nullptr, argv, environ) != 0) return false;
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0)
+        if (errno != EINTR) return false;
+    return WIFEXITED(status) && WEXITSTATUS(status) == 0;
+}
+
 bool load_texture(const std::string& path, Image8& out, std::string* why) {
     std::string ext;
     size_t dot = path.find_last_of('.');
@@ -120,14 +147,15 @@ bool load_texture(const std::string& path, Image8& out, std::string* why) {
     }
     std::string final_path = path, temp;
     if (ext == ".jpg" || ext == ".jpeg" || ext == ".png") {
-        // Same conversion the reference performs, but into a process-unique temporary file.
-        temp = "/tmp/rt_texture_conv_" + std::to_string(static_cast<long>(getpid())) + ".ppm";
-        std::string script = "import sys\ntry:\n   from PIL import Image\n   img = Image.open('" + path +
-                             "')\n   img = img.convert('RGB')\n   img.save('" + temp +
-                             "')\nexcept Exception as e:\n   print(e)\n   sys.exit(1)";
-        int ret = std::system(("python3 -c \"" + script + "\"").c_str());
-        if (ret != 0) ret = std::system(("python -c \"" + script + "\"").c_str());
-        if (ret == 0) final_path = temp;
+        // Same conversion the reference performs (PIL: open, convert('RGB'), save as PPM; python3, else python), into a
+        // temporary file of its own (mkstemp: unpredictable name, no collision between threads or processes).
+        char name[] = "/tmp/rt_texture_XXXXXX";
+        const int fd = mkstemp(name);
+        if (fd >= 0) {
+            close(fd);
+            temp = name;
+            if (convert_with_pil("python3", path, temp) || convert_with_pil("python", path, temp)) final_path = temp;
+        }
     }
     bool ok = true;
     try {

@@ -16,7 +16,8 @@ namespace rt {
 hipError_t launch_render_mega(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
                               hipStream_t stream);
 
-// Device memory the wavefront schedule keeps between calls (owned by the scene; freed with the scene).
+// Device memory the wavefront schedule keeps between calls: one workspace per HIP stream, process-wide (api.cpp keeps the
+// pool), so that queues outlive the scenes rendered through them; freed by rt_release_workspaces / rt_shutdown.
 struct WavefrontWorkspace {
     size_t capacity = 0;                 // rays per queue
     std::vector<void*> queues;           // RayRec[capacity] each
@@ -34,6 +35,11 @@ struct WavefrontWorkspace {
     size_t grow = 1;                     // queue headroom factor, raised once when a frame's ray tree outgrew the queues
     size_t grown_capacity = 0;           // ... and the capacity that was granted then (may exceed the default maximum)
     bool levels_overflowed = false;      // a frame's ray tree outgrew the queues when its levels were enqueued without round trips
+    unsigned long long overflowed_scene = 0;   // ... and the scene (DScene::serial) it belonged to: other scenes try again
+    // fixed: the workspace lives in memory the caller provided (the library's static scratch array, rt_render_device_noalloc):
+    // nothing is allocated, grown, freed or timed with events; a ray tree that needs more queues than there are fails.
+    bool fixed = false;
+    unsigned* host_readback = nullptr;   // fixed: pinned host words for the queue-size read-backs (else pageable stack words)
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);
 
@@ -46,5 +52,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
 // Device time of the k_traverse launches enqueued through `ws` since the last collection (their stream must have been
 // synchronised: hipErrorNotReady otherwise), and how many launches that was.
 hipError_t wavefront_traverse_time(WavefrontWorkspace& ws, double* ms_out, unsigned* launches_out);
+
+// Allocate (or grow to) `n_queues` queues of `rays_per_queue` rays for this workspace and touch every page, so that the
+// first frame rendered through it pays neither the allocation nor the first touch (rt_reserve).
+hipError_t wavefront_reserve(WavefrontWorkspace& ws, size_t rays_per_queue, int n_queues, hipStream_t stream);
 
 }  // namespace rt

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "device_rt.h"
@@ -773,6 +774,7 @@ struct Driver {
     int acquire() {
         for (size_t i = 0; i < ws.queues.size(); ++i)
             if (!ws.in_use[i]) { ws.in_use[i] = 1; return (int)i; }
+        if (ws.fixed) { ok(hipErrorOutOfMemory); return -1; }   // the ray tree needs more queues than the caller's memory holds
         void *q = nullptr, *h = nullptr;
         if (!ok(hipMalloc(&q, ws.capacity * sizeof(RayRec)))) return -1;
         if (!ok(hipMalloc(&h, ws.capacity * sizeof(HitRec)))) { (void)hipFree(q); return -1; }
@@ -801,7 +803,7 @@ struct Driver {
         return ws.events[ws.events_used++];
     }
     template <int F> void launch_traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
-        const bool timed = ws.events_used + 2 <= kMaxTimedEvents;
+        const bool timed = !ws.fixed && ws.events_used + 2 <= kMaxTimedEvents;
         hipEvent_t e0 = timed ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
         if (e1) (void)hipEventRecord(e0, stream);
         launch_traverse_kernel<F>(q, n, n_device);
@@ -869,13 +871,15 @@ struct Driver {
             q = qo;
             bound = std::min<size_t>(ws.capacity, bound * fanout(level));
         }
-        unsigned res[2] = {0, 0};
+        unsigned local[4] = {0, 0, 0, 0};
+        unsigned* res = ws.host_readback ? ws.host_readback : local;   // [0] last queue's size, [1] overflow flag, [2..3] ray total
         unsigned long long total = 0;
         if (err == hipSuccess) {
             ok(hipMemcpyAsync(&res[0], cnt + (level & 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
             ok(hipMemcpyAsync(&res[1], ws.counters + 2, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            ok(hipMemcpyAsync(&total, ws.stats, sizeof(total), hipMemcpyDeviceToHost, stream));
+            ok(hipMemcpyAsync(&res[2], ws.stats, sizeof(total), hipMemcpyDeviceToHost, stream));
             ok(hipStreamSynchronize(stream));
+            memcpy(&total, &res[2], sizeof(total));
         }
         if (err != hipSuccess) { release(q); return 0; }
         if (res[1]) {
@@ -885,13 +889,14 @@ struct Driver {
             // either, this stream's frames stay on the level-by-level path.
             release(q);
             size_t free_bytes = 0, total_bytes = 0;
-            (void)hipMemGetInfo(&free_bytes, &total_bytes);
+            if (!ws.fixed) (void)hipMemGetInfo(&free_bytes, &total_bytes);
             const size_t bigger = std::min(ws.capacity * 2, max_capacity);
-            if (ws.grow <= 2 && bigger > ws.capacity && free_bytes >= 8 * bigger * (sizeof(RayRec) + sizeof(HitRec))) {
+            if (!ws.fixed && ws.grow <= 2 && bigger > ws.capacity && free_bytes >= 8 * bigger * (sizeof(RayRec) + sizeof(HitRec))) {
                 ws.grow *= 2;
                 ws.grown_capacity = bigger;
             } else {
                 ws.levels_overflowed = true;
+                ws.overflowed_scene = S.serial;
             }
             return 1;
         }
@@ -921,14 +926,16 @@ struct Driver {
             if (qo < 0) break;
             if (!ok(hipMemsetAsync(ws.counters + 1, 0, 2 * sizeof(unsigned), stream))) { release(qo); break; }
             shade(q, start, m, qo);
-            unsigned res[2] = {0, 0};
-            if (!ok(hipMemcpyAsync(res, ws.counters + 1, sizeof(res), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
+            unsigned local[2] = {0, 0};
+            unsigned* res = ws.host_readback ? ws.host_readback : local;
+            if (!ok(hipMemcpyAsync(res, ws.counters + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
                 release(qo);
                 break;
             }
             if (res[1]) { ok(hipErrorOutOfMemory); release(qo); break; }  // queue overflow: cannot happen with the batching above
             if (start + m >= n) { release(q); q = -1; }                    // input fully consumed: its buffers may be reused below
-            process(qo, res[0], level + 1);
+            const unsigned n_children = res[0];
+            process(qo, n_children, level + 1);
         }
         if (q >= 0) release(q);
     }
@@ -937,61 +944,82 @@ struct Driver {
 }  // namespace
 
 void wavefront_workspace_free(WavefrontWorkspace& ws) {
-    for (void* p : ws.queues) (void)hipFree(p);
-    for (void* p : ws.hit_buffers) (void)hipFree(p);
+    if (!ws.fixed) {
+        for (void* p : ws.queues) (void)hipFree(p);
+        for (void* p : ws.hit_buffers) (void)hipFree(p);
+        if (ws.accum) (void)hipFree(ws.accum);
+        if (ws.counters) (void)hipFree(ws.counters);
+        if (ws.stats) (void)hipFree(ws.stats);
+    }
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
-    if (ws.accum) (void)hipFree(ws.accum);
-    if (ws.counters) (void)hipFree(ws.counters);
-    if (ws.stats) (void)hipFree(ws.stats);
     ws = WavefrontWorkspace();
 }
 
-hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear) {
-    const size_t npix = (size_t)params.part_rows * params.width;
-    if (npix == 0) return hipSuccess;
+namespace {
+
+bool frame_may_emit(const DScene& scene, const DParams& params) {
+    return !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
+}
+// worst-case children of one primary ray
+size_t first_level_fanout(const DScene& scene, const DParams& params) {
+    const size_t refl = (params.max_depth < params.max_bounces) ? 1 : (size_t)std::max(params.glossy_samples, 1);
+    return refl + 1 + (params.shadows ? 2ull * (size_t)scene.n_lights * (size_t)params.shadow_samples : 0ull);
+}
+// levels of the ray tree: radiance rays of depth max_depth .. 1, the shadow rays of the last of them, and a few
+// segments of shadow rays that continue through transmitting surfaces (longer chains are finished level by level)
+int tree_levels(const DScene& scene, const DParams& params) {
+    return std::max(1, params.max_depth) + (params.shadows ? 1 : 0) + ((params.shadows && scene.transparent_materials) ? 4 : 0);
+}
+
+hipError_t drop_queues(WavefrontWorkspace& ws, hipStream_t stream) {
+    hipError_t e = hipStreamSynchronize(stream);   // nothing of this stream's workspace is in flight afterwards
+    if (e != hipSuccess) return e;
+    for (void* p : ws.queues) (void)hipFree(p);
+    for (void* p : ws.hit_buffers) (void)hipFree(p);
+    ws.queues.clear();
+    ws.hit_buffers.clear();
+    ws.in_use.clear();
+    return hipSuccess;
+}
+
+hipError_t ensure_small_buffers(WavefrontWorkspace& ws) {
+    if (ws.counters) return hipSuccess;
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), (kNextBase + kXcds * kNextStride) * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    ws.compute_units = cus;
+    const char* rpl = getenv("RT_RAYS_PER_LANE");
+    ws.rays_per_lane = rpl ? std::max(1, atoi(rpl)) : RT_RAYS_PER_LANE;
+    return hipSuccess;
+}
+
+// Sizes and allocates what a frame needs of an owned (not fixed) workspace.
+hipError_t prepare_workspace(const DScene& scene, const DParams& params, hipStream_t stream, WavefrontWorkspace& ws, size_t npix,
+                             bool may_emit, size_t* max_queue_rays) {
     hipError_t e;
     // Queue capacity: what one chunk of primary rays and its children need, up to RT_QUEUE_RAYS (default 2^26 rays =
     // 9.7 GB per queue; a frame that needs more is rendered in chunks of rows x samples and batches of rays).  Large
     // queues mean few batches, i.e. few launches and few host round trips per level: HBM is there to be used.
-    const bool may_emit = !params.normals && ((params.shadows && scene.n_lights > 0) || scene.spawning_materials != 0);
-    size_t max_queue_rays = 0;
-    {
-        const char* env = getenv("RT_QUEUE_RAYS");
-        const size_t env_cap = env ? strtoull(env, nullptr, 10) : 0;
-        const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : std::max(kDefaultMaxQueueRays, ws.grown_capacity), size_t(1) << 31);   // slots are 32-bit
-        size_t fan = 1;
-        if (may_emit) {
-            const size_t refl = (params.max_depth < params.max_bounces) ? 1 : (size_t)std::max(params.glossy_samples, 1);
-            fan = refl + 1 + (params.shadows ? 2ull * (size_t)scene.n_lights * (size_t)params.shadow_samples : 0ull);
-        }
-        size_t want = kMinQueueRays;
-        const char* head = getenv("RT_QUEUE_HEADROOM");   // queues this many times larger than the first level needs (deep ray trees)
-        const size_t headroom = std::max<size_t>(1, head ? strtoull(head, nullptr, 10) : 1) * ws.grow;
-        while (want < max_cap && want < npix * (size_t)params.spp * fan * headroom) want <<= 1;
-        want = std::min(want, max_cap);
-        max_queue_rays = env_cap >= 4096 ? max_cap : kGrownMaxQueueRays;   // how far run_levels may grow the queues
-        if (ws.capacity != 0 && ws.capacity < want) {   // a larger frame than before: drop the queues (nothing is in flight on this stream's workspace after the sync)
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-            for (void* p : ws.queues) (void)hipFree(p);
-            for (void* p : ws.hit_buffers) (void)hipFree(p);
-            ws.queues.clear();
-            ws.hit_buffers.clear();
-            ws.in_use.clear();
-            ws.capacity = want;
-        }
-        if (ws.capacity == 0) ws.capacity = want;
+    const char* env = getenv("RT_QUEUE_RAYS");
+    const size_t env_cap = env ? strtoull(env, nullptr, 10) : 0;
+    const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : std::max(kDefaultMaxQueueRays, ws.grown_capacity), size_t(1) << 31);   // slots are 32-bit
+    const size_t fan = may_emit ? first_level_fanout(scene, params) : 1;
+    size_t want = kMinQueueRays;
+    const char* head = getenv("RT_QUEUE_HEADROOM");   // queues this many times larger than the first level needs (deep ray trees)
+    const size_t headroom = std::max<size_t>(1, head ? strtoull(head, nullptr, 10) : 1) * ws.grow;
+    while (want < max_cap && want < npix * (size_t)params.spp * fan * headroom) want <<= 1;
+    want = std::min(want, max_cap);
+    *max_queue_rays = env_cap >= 4096 ? max_cap : kGrownMaxQueueRays;   // how far run_levels may grow the queues
+    // a larger frame than before, or RT_QUEUE_RAYS now asks for smaller queues than this stream holds (tests): drop the queues
+    if (ws.capacity != 0 && (ws.capacity < want || ws.capacity > max_cap)) {
+        if ((e = drop_queues(ws, stream)) != hipSuccess) return e;
+        ws.capacity = want;
     }
-    if (!ws.counters) {
-        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), (kNextBase + kXcds * kNextStride) * sizeof(unsigned))) != hipSuccess) return e;
-        if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return e;
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        ws.compute_units = cus;
-        const char* rpl = getenv("RT_RAYS_PER_LANE");
-        ws.rays_per_lane = rpl ? std::max(1, atoi(rpl)) : RT_RAYS_PER_LANE;
-    }
+    if (ws.capacity == 0) ws.capacity = want;
+    if ((e = ensure_small_buffers(ws)) != hipSuccess) return e;
     if (ws.accum_pixels < npix) {
         if (ws.accum) (void)hipFree(ws.accum);
         ws.accum = nullptr;
@@ -999,6 +1027,47 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         if ((e = hipMalloc(reinterpret_cast<void**>(&ws.accum), npix * 3 * sizeof(double))) != hipSuccess) return e;
         ws.accum_pixels = npix;
     }
+    return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t wavefront_reserve(WavefrontWorkspace& ws, size_t rays_per_queue, int n_queues, hipStream_t stream) {
+    if (ws.fixed) return hipErrorInvalidValue;
+    hipError_t e;
+    size_t want = kMinQueueRays;
+    while (want < rays_per_queue && want < (size_t(1) << 31)) want <<= 1;
+    if (ws.capacity < want) {
+        if ((e = drop_queues(ws, stream)) != hipSuccess) return e;
+        ws.capacity = want;
+        ws.grown_capacity = std::max(ws.grown_capacity, want);   // a later frame keeps this size even above the default maximum
+    }
+    if ((e = ensure_small_buffers(ws)) != hipSuccess) return e;
+    while ((int)ws.queues.size() < n_queues) {
+        void *q = nullptr, *h = nullptr;
+        if ((e = hipMalloc(&q, ws.capacity * sizeof(RayRec))) != hipSuccess) return e;
+        if ((e = hipMalloc(&h, ws.capacity * sizeof(HitRec))) != hipSuccess) { (void)hipFree(q); return e; }
+        ws.queues.push_back(q);
+        ws.hit_buffers.push_back(h);
+        ws.in_use.push_back(0);
+    }
+    // first touch of every page here, not inside the first frame
+    for (size_t i = 0; i < ws.queues.size(); ++i) {
+        if ((e = hipMemsetAsync(ws.queues[i], 0, ws.capacity * sizeof(RayRec), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(ws.hit_buffers[i], 0, ws.capacity * sizeof(HitRec), stream)) != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(stream);
+}
+
+hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear) {
+    const size_t npix = (size_t)params.part_rows * params.width;
+    if (npix == 0) return hipSuccess;
+    hipError_t e;
+    const bool may_emit = frame_may_emit(scene, params);
+    size_t max_queue_rays = ws.capacity;
+    if (!ws.fixed && (e = prepare_workspace(scene, params, stream, ws, npix, may_emit, &max_queue_rays)) != hipSuccess) return e;
+    if (ws.levels_overflowed && ws.overflowed_scene != scene.serial) ws.levels_overflowed = false;   // another scene: try again
     if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
 
     if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
@@ -1026,9 +1095,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     const bool one_chunk = rows_per_chunk >= params.part_rows && ns >= params.spp;
     // (a scene whose ray tree outgrew the queues once on this stream is not tried again)
     const bool optimistic = may_emit && one_chunk && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
-    // levels of the ray tree: radiance rays of depth max_depth .. 1, the shadow rays of the last of them, and a few
-    // segments of shadow rays that continue through transmitting surfaces (longer chains are finished level by level)
-    const int levels = std::max(1, params.max_depth) + (params.shadows ? 1 : 0) + ((params.shadows && scene.transparent_materials) ? 4 : 0);
+    const int levels = tree_levels(scene, params);
     for (int row0 = 0; row0 < params.part_rows && D.err == hipSuccess; row0 += rows_per_chunk) {
         const int rows = std::min(rows_per_chunk, params.part_rows - row0);
         for (int s0 = 0; s0 < params.spp && D.err == hipSuccess; s0 += ns) {
@@ -1042,9 +1109,12 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
                 const int lr = D.run_levels(q, (unsigned)n, levels);
                 if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] capacity %zu grow %zu -> %s\n", ws.capacity, ws.grow, lr == 0 ? "done" : "overflow");
                 if (lr == 0) continue;
-                // a level outgrew its queue: start the frame over, level by level with batches
+                // a level outgrew its queue: start the frame over, level by level with batches; what the aborted attempt
+                // added to the accumulators, the test counters and the traversal timing is dropped
                 if (D.err != hipSuccess) break;
                 if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
+                if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+                ws.events_used = first_event;
                 D.rays_traced = 0;
                 if ((q = D.acquire()) < 0) break;
                 hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,

@@ -7,6 +7,9 @@
 // Added (no counterpart in the reference, whose paths are hard-coded relative to Code/<build>/):
 //   --scene PATH --config PATH --out PATH --texture-root DIR --device N --seed N --d0 --megakernel --pfm PATH
 //   --bvh-builder {sah|sah_gpu|lbvh|median}   (rt_set_bvh_builder: host threads / built on the GPU / the reference's topology)
+//   --gpus N   one process per GPU (devices --device .. --device + N - 1), forked here before anything touches a GPU: every
+//              rank renders its interleaved row tiles, the slices are gathered on rank 0 over RCCL (rt_render_gathered),
+//              and rank 0 -- this process -- prints and writes what the single-GPU run does
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -19,6 +22,11 @@
 #include <regex>
 #include <string>
 #include <vector>
+
+#include <csignal>
+#include <sys/socket.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "../../include/rt_mi355x.h"
 
@@ -35,7 +43,7 @@ struct Options {
     bool use_bvh = true, shadows = false, glossy = false, parallel = false, fresnel = false, normals = false;
     bool timing = false, bvh_testing = false, d0 = false, megakernel = false;
     int bvh_builder = RT_BVH_DEFAULT;
-    int run_count = 1, tonemap = 0, device = 0;
+    int run_count = 1, tonemap = 0, device = 0, gpus = 1;
     bool have_aa = false, have_exposure = false, have_shutter = false;
     int aa = 1;
     double exposure = 1.0, shutter = 0.0;
@@ -90,6 +98,7 @@ int main(int argc, char* argv[]) {
             else if (a == "--out" && i + 1 < argc) o.out = argv[++i];
             else if (a == "--texture-root" && i + 1 < argc) o.texture_root = argv[++i];
             else if (a == "--device" && i + 1 < argc) o.device = std::stoi(argv[++i]);
+            else if (a == "--gpus" && i + 1 < argc) o.gpus = std::max(1, std::stoi(argv[++i]));
             else if (a == "--seed" && i + 1 < argc) o.seed = std::stoull(argv[++i]);
             else if (a == "--d0") o.d0 = true;
             else if (a == "--megakernel") o.megakernel = true;
@@ -122,9 +131,83 @@ int main(int argc, char* argv[]) {
     p.schedule = o.megakernel ? RT_SCHEDULE_MEGAKERNEL : RT_SCHEDULE_WAVEFRONT;
 
     (void)rt_set_bvh_builder(o.bvh_builder);
-    if (rt_init(o.device) != RT_OK) {
-        std::cerr << "An error occurred: " << rt_last_error() << std::endl;
-        return 1;
+    // --gpus N: ranks 1 .. N-1 are forked here, before the first HIP call of this process.  Each reports over a socket pair
+    // whether it got its GPU, and only when all have does rank 0 create the RCCL id and hand it out (a communicator whose
+    // ranks never all arrive would wait for ever).  All ranks then run the same sequence of renders (rt_render_gathered is
+    // collective); only rank 0 prints, times and writes files.
+    int rank = 0;
+    std::vector<pid_t> children;
+    std::vector<int> id_pipes;
+    int my_pipe = -1;
+    std::signal(SIGPIPE, SIG_IGN);
+    for (int r = 1; r < o.gpus; ++r) {
+        int fd[2];
+        if (socketpair(AF_UNIX, SOCK_STREAM, 0, fd) != 0) { std::cerr << "An error occurred: socketpair() failed" << std::endl; return 1; }
+        std::cout.flush();
+        const pid_t pid = fork();
+        if (pid < 0) { std::cerr << "An error occurred: fork() failed" << std::endl; return 1; }
+        if (pid == 0) {
+            rank = r;
+            close(fd[1]);
+            for (int w : id_pipes) close(w);
+            id_pipes.clear();
+            children.clear();
+            my_pipe = fd[0];
+            std::cout.setstate(std::ios_base::failbit);   // one voice: rank 0's
+            break;
+        }
+        close(fd[0]);
+        children.push_back(pid);
+        id_pipes.push_back(fd[1]);
+    }
+    auto finish = [&](int code) {   // rank 0 waits for the others; any failure fails the run
+        for (pid_t c : children) {
+            int status = 0;
+            if (waitpid(c, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) code = code ? code : 1;
+        }
+        return code;
+    };
+    const bool have_gpu = rt_init(o.device + rank) == RT_OK;
+    if (!have_gpu) std::cerr << "An error occurred: " << (o.gpus > 1 ? "rank " + std::to_string(rank) + ": " : std::string()) << rt_last_error() << std::endl;
+    if (rank > 0) {
+        const char ready = have_gpu ? 1 : 0;
+        if (write(my_pipe, &ready, 1) != 1 || !have_gpu) return 1;
+    } else if (!have_gpu) {
+        for (int w : id_pipes) close(w);   // the other ranks see end of file and leave
+        return finish(1);
+    }
+    if (o.gpus > 1) {
+        unsigned char id[RT_COMM_ID_BYTES];
+        bool ok = true;
+        if (rank == 0) {
+            for (int w : id_pipes) {
+                char ready = 0;
+                if (read(w, &ready, 1) != 1 || ready != 1) ok = false;
+            }
+            if (!ok) {
+                std::cerr << "An error occurred: --gpus " << o.gpus << ": not every rank got its GPU; nothing rendered" << std::endl;
+                for (int w : id_pipes) close(w);
+                return finish(1);
+            }
+            ok = rt_comm_unique_id(id) == RT_OK;
+            for (int w : id_pipes) {
+                if (ok) ok = write(w, id, sizeof(id)) == (ssize_t)sizeof(id);
+                close(w);
+            }
+        } else {
+            size_t got = 0;
+            while (got < sizeof(id)) {
+                const ssize_t n = read(my_pipe, id + got, sizeof(id) - got);
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            close(my_pipe);
+            ok = got == sizeof(id);
+        }
+        if (!ok || rt_comm_init(rank, o.gpus, id) != RT_OK) {
+            std::cerr << "An error occurred: rank " << rank << ": " << (ok ? rt_last_error() : "no RCCL id from rank 0") << std::endl;
+            return finish(1);
+        }
     }
 
     // render_scene_func of main.cpp:229-359: returns elapsed seconds of load + build + render (the file write is outside)
@@ -146,19 +229,20 @@ int main(int argc, char* argv[]) {
         }
         const int w = d->camera.resolution_x, h = d->camera.resolution_y;
         std::cout << "Rendering scene (" << w << "x" << h << ") with " << p.samples_per_pixel << " samples per pixel..." << std::endl;
-        std::cout << "Device: HIP device " << o.device << " (" << rt_version() << ")" << std::endl;
+        std::cout << "Device: HIP device " << o.device << (o.gpus > 1 ? " .. " + std::to_string(o.device + o.gpus - 1) + ", interleaved row tiles, RCCL gather" : std::string())
+                  << " (" << rt_version() << ")" << std::endl;
         std::vector<uint8_t> img(static_cast<size_t>(w) * h * 3);
         RtRenderParams q = p;
         q.use_bvh = use_bvh ? 1 : 0;
         RtStats st{};
-        bool ok = rt_render(sc, &q, img.data(), &st) == RT_OK;
+        bool ok = (o.gpus > 1 ? rt_render_gathered(sc, &q, img.data(), &st) : rt_render(sc, &q, img.data(), &st)) == RT_OK;
         if (!ok) std::cerr << "An error occurred: " << rt_last_error() << std::endl;
         seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         if (ok) {
             std::cout << "Rendering: 100% [" << h << "/" << h << "]" << std::endl;
             std::cout << "Rays: " << st.rays << ", device " << st.kernel_ms << " ms (" << (st.kernel_ms > 0 ? st.rays / st.kernel_ms / 1e3 : 0.0)
                       << " Mrays/s)" << std::endl;
-            if (!output_path.empty()) {
+            if (!output_path.empty() && rank == 0) {
                 if (rt_write_ppm(output_path.c_str(), w, h, img.data()) != RT_OK) {
                     std::cerr << "An error occurred: " << rt_last_error() << std::endl;
                     ok = false;
@@ -166,7 +250,7 @@ int main(int argc, char* argv[]) {
                     std::cout << "Image saved to '" << output_path << "'." << std::endl;
                 }
             }
-            if (ok && !o.pfm_path.empty()) {   // linear radiance of the same frame (same seed: same samples), before tone mapping
+            if (ok && !o.pfm_path.empty() && o.gpus == 1) {   // linear radiance of the same frame (same seed: same samples), before tone mapping
                 std::vector<double> lin(static_cast<size_t>(w) * h * 3);
                 RtRenderParams ql = q;
                 ql.schedule = RT_SCHEDULE_WAVEFRONT;
@@ -188,11 +272,13 @@ int main(int argc, char* argv[]) {
         const std::string out_dir = "../../Output/testing/" + timestamp();
         const std::string src_dir = "../../ASCII/BVH_tests";
         try {
-            fs::create_directories(out_dir);
-            std::cout << "Output directory created: " << out_dir << std::endl;
-            if (fs::exists(src_dir)) fs::copy(src_dir, out_dir + "/BVH_tests", fs::copy_options::recursive | fs::copy_options::overwrite_existing);
-            else std::cerr << "Warning: BVH_tests directory not found at " << src_dir << std::endl;
-            std::ofstream(out_dir + "/flags.txt") << "Flags used: " << o.all_args << std::endl;
+            if (rank == 0) {
+                fs::create_directories(out_dir);
+                std::cout << "Output directory created: " << out_dir << std::endl;
+                if (fs::exists(src_dir)) fs::copy(src_dir, out_dir + "/BVH_tests", fs::copy_options::recursive | fs::copy_options::overwrite_existing);
+                else std::cerr << "Warning: BVH_tests directory not found at " << src_dir << std::endl;
+                std::ofstream(out_dir + "/flags.txt") << "Flags used: " << o.all_args << std::endl;
+            }
             struct Item { int x; std::string path; };
             std::vector<Item> items;
             std::regex re(R"(scene_?(\d+)\.txt)", std::regex::icase);
@@ -206,10 +292,11 @@ int main(int argc, char* argv[]) {
                 }
             if (items.empty()) {
                 std::cerr << "No matching scene files found! Please check filenames in " << src_dir << std::endl;
-                return 1;
+                return finish(1);
             }
             std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.x < b.x; });
-            std::ofstream f_bvh(out_dir + "/bvh_test.txt"), f_no(out_dir + "/no_bvh_test.txt");
+            std::ofstream f_bvh, f_no;
+            if (rank == 0) { f_bvh.open(out_dir + "/bvh_test.txt"); f_no.open(out_dir + "/no_bvh_test.txt"); }
             for (const auto& it : items) {
                 std::cout << "\n--- Testing Scene X=" << it.x << " ---" << std::endl;
                 for (int mode = 0; mode < 2; ++mode) {
@@ -218,30 +305,30 @@ int main(int argc, char* argv[]) {
                         std::cout << "Run " << (k + 1) << "/3 " << (mode == 0 ? "[BVH ON]" : "[BVH OFF]") << std::endl;
                         std::string img = k == 0 ? out_dir + (mode == 0 ? "/bvh_" : "/no_bvh_") + std::to_string(it.x) + ".ppm" : "";
                         double s = 0;
-                        if (!render_scene(it.path, mode == 0, img, s)) return 1;
+                        if (!render_scene(it.path, mode == 0, img, s)) return finish(1);
                         total += s;
                     }
-                    (mode == 0 ? f_bvh : f_no) << total / 3.0 << " " << it.x << std::endl;
+                    if (rank == 0) (mode == 0 ? f_bvh : f_no) << total / 3.0 << " " << it.x << std::endl;
                 }
             }
             std::cout << "\nBVH Testing Complete. Results saved to " << out_dir << std::endl;
         } catch (const std::exception& e) {
             std::cerr << "Error during BVH testing: " << e.what() << std::endl;
-            return 1;
+            return finish(1);
         }
     } else {  // main.cpp:481-566
         std::string ts, out_dir;
         if (o.timing) {
             ts = timestamp();
             out_dir = "../../Output/testing/" + ts;
-            try {
+            if (rank == 0) try {
                 fs::create_directories(out_dir);
                 std::cout << "Output directory created: " << out_dir << std::endl;
                 fs::copy(o.scene, out_dir + "/scene.txt", fs::copy_options::overwrite_existing);
                 std::cout << "Saved copy of scene.txt to output folder." << std::endl;
             } catch (const std::exception& e) {
                 std::cerr << "Error creating output directory: " << e.what() << std::endl;
-                return 1;
+                return finish(1);
             }
         }
         std::vector<std::pair<double, std::string>> runs;
@@ -257,7 +344,7 @@ int main(int argc, char* argv[]) {
                 std::cout << "Render complete! Image saved to '" << file << "'." << std::endl;
             }
         }
-        if (o.timing && rc == 0) {  // main.cpp:546-561
+        if (o.timing && rc == 0 && rank == 0) {  // main.cpp:546-561
             std::ofstream log(out_dir + "/timing_log.txt");
             if (log.is_open()) {
                 log << "args: [" << o.all_args << "]\n";
@@ -269,6 +356,7 @@ int main(int argc, char* argv[]) {
         }
     }
     rt_config_destroy(cfg);
+    if (o.gpus > 1) (void)rt_comm_destroy();
     rt_shutdown();
-    return rc;
+    return finish(rc);
 }

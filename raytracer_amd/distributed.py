@@ -1,7 +1,13 @@
-"""Multi-GPU frame assembly: one process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI on ROCm, "gloo"
-for CPU tests).  The reference shares one `Image` between OpenMP threads (Code/main.cpp:242,279-320); here the frame
-is cut into row tiles, tile k belongs to rank k % world, every rank renders its tiles into a compact u8 slice and the
-slices are gathered to rank 0 and de-interleaved.  No other collective is needed: pixels are independent."""
+"""Multi-GPU frame assembly: one process per GPU.  The reference shares one `Image` between OpenMP threads
+(Code/main.cpp:242,279-320); here the frame is cut into row tiles, tile k belongs to rank k % world, every rank renders
+its tiles into a compact u8 slice and the slices are gathered to rank 0 and de-interleaved.  No other collective is
+needed: pixels are independent.
+
+On GPUs the exchange is the library's own (C-ABI rt_gather_frames: grouped ncclSend / ncclRecv over RCCL / xGMI and
+the k_deinterleave HIP kernel, raytracer_amd/csrc/comm.hip); `FrameGather` only owns the buffers and calls it, and
+`init_comm` hands the RCCL unique id from rank 0 to the others through torch.distributed, which the launcher
+(torchrun) has set up anyway.  With the "gloo" backend (CPU tests, rehearsals of the multi-rank control flow on a box
+with fewer GPUs than ranks) the same assembly is done with torch.distributed.gather + index_select."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -27,6 +33,22 @@ def deinterleave_index(height, tile_rows, world, rows_per_slot):
     return src
 
 
+def init_comm(device=None):
+    """Create the library's RCCL communicator over the ranks of the default torch.distributed group (no-op for one
+    rank, or when it exists): rank 0's unique id is broadcast as a byte tensor."""
+    if not dist.is_initialized() or dist.get_world_size() == 1 or rt.comm_world() == dist.get_world_size():
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    on_gpu = dist.get_backend() == "nccl"
+    uid = torch.zeros(rt.RT_COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(rt.comm_unique_id()), dtype=torch.uint8).clone()
+    if on_gpu:
+        uid = uid.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(uid, src=0)
+    rt.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+
 class FrameGather:
     """Pre-allocated buffers for gathering padded slices [max_rows, W, 3] u8 to rank 0 and rebuilding the frame.
 
@@ -43,7 +65,12 @@ class FrameGather:
         self.slices = torch.zeros((frames, self.max_rows, width, 3), dtype=torch.uint8, device=device)
         self.slice = self.slices[0]
         self.gathered, self.gather_buffer, self.frames, self.frame, self.index, self._parts = None, None, None, None, None, None
-        if self.rank == 0:
+        # the library's exchange (RCCL + k_deinterleave) whenever its communicator spans this group
+        self.native = self.world > 1 and self.slices.is_cuda and rt.comm_world() == self.world and rt.comm_rank() == self.rank
+        if self.rank == 0 and self.native:
+            self.frames = torch.empty((frames, height, width, 3), dtype=torch.uint8, device=device)
+            self.frame = self.frames[0]
+        elif self.rank == 0:
             self.frames = torch.empty((frames, height, width, 3), dtype=torch.uint8, device=device)
             self.frame = self.frames[0]
             if self.world > 1:
@@ -63,6 +90,12 @@ class FrameGather:
         or the batch of frames, else None."""
         if self.world == 1:
             return self.slice[: self.height] if self.batch == 1 else self.slices[:, : self.height]
+        if self.native:
+            rt.gather_frames(self.slices.data_ptr(), self.batch, self.width, self.height, self.tile_rows,
+                             self.frames.data_ptr() if self.rank == 0 else None, stream=torch.cuda.current_stream().cuda_stream)
+            if self.rank == 0:
+                return self.frame if self.batch == 1 else self.frames
+            return None
         if self.slices.is_cuda and dist.get_backend() == "gloo":
             # gloo gathers host tensors only (rehearsals of the multi-rank path on a box with fewer GPUs than ranks)
             host = [torch.empty(self.slices.shape, dtype=torch.uint8) for _ in range(self.world)] if self.rank == 0 else None

@@ -69,3 +69,21 @@ def test_gather_and_deinterleave(tmp_path, world, height, tile, frames):
            "--master-port", str(_free_port()), str(script)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_bench_never_reports_one_gpu_for_a_multi_gpu_request():
+    """`python bench.py --gpus 2` with no launcher and fewer than 2 visible GPUs (none here): non-zero exit and no result
+    line -- never a single-rank number under an N > 1 request.  (With the GPUs present it starts the ranks itself:
+    tests/test_gpu_comm.py.)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a machine with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2 asked for" in p.stderr and "{" not in p.stdout

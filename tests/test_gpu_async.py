@@ -176,3 +176,59 @@ def test_a_level_that_outgrows_its_queue_restarts_the_frame_level_by_level(gpu, 
     assert int(st.rays) == int(st_ref.rays)
     mx, nd, _ = helpers.diff_stats(img, ref)
     assert mx <= 1 and nd <= 1e-3 * img.size
+
+
+def test_render_on_torchs_default_stream_is_ordered_with_torch_work(gpu):
+    """hip_stream NULL is HIP's null stream == torch's default stream: a torch op enqueued right after the render reads the
+    finished frame without any synchronisation in between (the multi-GPU recipe of INTEGRATION.md relies on this)."""
+    scene_file, params, golden = helpers.load_case("c1_shadows_fresnel")
+    scene = rt.Scene(scene_file)
+    ref = scene.render(params)
+    dev = torch.device("cuda", 0)
+    for stream_arg in (None, torch.cuda.current_stream(dev).cuda_stream):
+        buf = torch.zeros(ref.shape, dtype=torch.uint8, device=dev)     # fill on the default stream, render behind it
+        scene.render_device(params, buf.data_ptr(), stream=stream_arg)
+        copy = buf.clone()                                              # default stream again: ordered behind the render
+        mx, nd, _ = helpers.diff_stats(copy.cpu().numpy(), ref)
+        assert mx <= 1 and nd <= 1e-3 * ref.size
+    # a frame without secondary rays is enqueued fully asynchronously: the same ordering must hold
+    scene.close()
+    scene_file, params, golden = helpers.load_case("bvh_100_shaded")
+    scene = rt.Scene(scene_file)
+    ref = scene.render(params)
+    buf = torch.zeros(ref.shape, dtype=torch.uint8, device=dev)
+    scene.render_device(params, buf.data_ptr())
+    assert np.array_equal(buf.clone().cpu().numpy(), ref)
+    scene.close()
+
+
+def test_queues_outlive_scenes_and_can_be_reserved(gpu):
+    """Workspaces belong to the stream, not the scene: rt_reserve allocates and touches them ahead of time, scenes come and
+    go, and frames stay the same; rt_release_workspaces frees them and the next render allocates again."""
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    before = torch.cuda.mem_get_info(dev)[0]
+    rt.reserve(stream.cuda_stream, 1 << 20, 3)       # 3 queues x 2^20 rays x 144 B = 453 MB
+    after = torch.cuda.mem_get_info(dev)[0]
+    assert before - after >= 0.9 * 3 * (1 << 20) * 144   # the allocator may reuse a few MB it kept
+    out = []
+    for name in ("c1_shadows_fresnel", "own_glass_env", "c1_shadows_fresnel"):
+        scene_file, params, golden = helpers.load_case(name)
+        scene = rt.Scene(scene_file)
+        buf = torch.zeros((scene.height, scene.width, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        scene.render_device(params, buf.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        assert helpers.diff_stats(buf.cpu().numpy(), golden)[0] <= 1
+        out.append(buf.cpu().numpy())
+        scene.close()
+    assert helpers.diff_stats(out[0], out[2])[0] <= 1
+    assert torch.cuda.mem_get_info(dev)[0] <= after + (64 << 20)   # closing scenes did not free the queues
+    rt.release_workspaces()
+    assert torch.cuda.mem_get_info(dev)[0] >= after + 0.9 * 3 * (1 << 20) * 144 - (64 << 20)
+    with pytest.raises(rt.RtError):
+        rt.reserve(stream.cuda_stream, 0, 1)
+    scene_file, params, golden = helpers.load_case("c1_shadows_fresnel")
+    scene = rt.Scene(scene_file)
+    assert helpers.diff_stats(scene.render(params), golden)[0] <= 1   # allocates again
+    scene.close()
