@@ -288,6 +288,18 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);
 
+/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has NO counterpart in the reference (which has no device): same pixels as
+ * rt_render_device with the wavefront schedule, but every buffer the kernels need beyond the scene and d_rgb8 -- ray
+ * queues, hit records, FP64 accumulators, queue counters -- lies in a 64 MiB __device__ array inside the library (one
+ * copy per GPU, held until the process ends), and the call allocates and frees nothing on the device.
+ * Limits (RT_ERR_LIMIT with a message): the rendered part (rt_part_rows x width) holds at most 2^18 pixels and is at most
+ * 1024 pixels wide -- larger frames are rendered in parts -- and the frame's ray tree must fit the queues that fit the
+ * array (one queue per ray-tree level; chains of shadow segments through many transmitting surfaces may not).
+ * All calls on a GPU share the array: calls that overlap on one GPU (different streams or threads) race; run them one
+ * after the other.  Returns when the last level has been enqueued on `hip_stream`, like rt_render_device. */
+int rt_render_device_noalloc(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* hip_stream);
+
 /* Ray queues of the wavefront schedule are kept per HIP stream for the life of the process, not per scene: a service that
  * opens and closes scenes keeps them.  rt_reserve allocates (or grows to) n_queues queues of rays_per_queue rays (144 bytes
  * per ray) for `hip_stream` and touches every page, so that the first frame rendered on that stream pays neither the

@@ -118,7 +118,7 @@ ABI_SYMBOLS = [
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
     "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
-    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_reserve",
+    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_render_device_noalloc", "rt_reserve",
     "rt_release_workspaces", "rt_comm_unique_id", "rt_comm_init", "rt_comm_rank", "rt_comm_world", "rt_comm_destroy",
     "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered",
 ]
@@ -168,6 +168,7 @@ def _load():
         "rt_bvh_order_device": (i32, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
+        "rt_render_device_noalloc": (i32, [vp, C.POINTER(RtRenderParams), vp, vp]),
         "rt_reserve": (i32, [vp, C.c_uint64, i32]), "rt_release_workspaces": (i32, []),
         "rt_comm_unique_id": (i32, [vp]), "rt_comm_init": (i32, [i32, i32, vp]), "rt_comm_rank": (i32, []),
         "rt_comm_world": (i32, []), "rt_comm_destroy": (i32, []),
@@ -532,6 +533,10 @@ class Scene:
         """Asynchronous render of this part's rows into device memory (see rt_render_device).  stream: a hipStream_t value
         (torch: `stream.cuda_stream`); None is the null stream, i.e. torch's default stream."""
         _check(lib.rt_render_device(self._h, C.byref(params), d_rgb8_ptr, d_counters_ptr, int(collect_counters), stream))
+
+    def render_device_noalloc(self, params, d_rgb8_ptr, stream=None):
+        """rt_render_device through the library's static workspace: no device allocation (see rt_render_device_noalloc)."""
+        _check(lib.rt_render_device_noalloc(self._h, C.byref(params), d_rgb8_ptr, stream))
 
     def traverse_time(self, stream=None):
         """(ms, launches) of the traversal-kernel launches enqueued on `stream` since the last call (stream synchronised)."""

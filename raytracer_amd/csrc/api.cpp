@@ -321,6 +321,7 @@ int rt_init(int device_id) {
     HIP_TRY(hipEventCreate(&g_dev.ev0));
     HIP_TRY(hipEventCreate(&g_dev.ev1));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_dev.d_counters), RT_N_COUNTERS * sizeof(uint64_t)));
+    HIP_TRY(wavefront_static_setup(dev));   // device address of the static scratch array of rt_render_device_noalloc
     g_dev.ready = true;
     return RT_OK;
 }
@@ -691,6 +692,28 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     else
         e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
                                     *workspace_of(st, true));
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_device_noalloc(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* hip_stream) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!d_rgb8) return fail(RT_ERR_INVALID, "d_rgb8 is NULL");
+    DParams dp;
+    int rc = make_dparams(scene, params, 0, &dp);
+    if (rc) return rc;
+    if (params->schedule != RT_SCHEDULE_WAVEFRONT) return fail(RT_ERR_INVALID, "rt_render_device_noalloc renders with the wavefront schedule");
+    if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
+    if (dp.part_rows == 0) return RT_OK;
+    const long long npix = static_cast<long long>(dp.part_rows) * dp.width;
+    if (npix > kStaticMaxPixels || dp.width > kStaticMaxWidth)
+        return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the part has " + std::to_string(npix) + " pixels, " + std::to_string(dp.width) +
+                                      " wide; the static workspace holds parts of at most " + std::to_string(kStaticMaxPixels) + " pixels, at most " +
+                                      std::to_string(kStaticMaxWidth) + " wide (render the frame in parts, or use rt_render_device)");
+    hipError_t e = launch_render_wavefront_static(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<hipStream_t>(hip_stream), g_dev.device);
+    if (e == hipErrorOutOfMemory)
+        return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the ray tree of this frame needs more queues than the static workspace (" +
+                                      std::to_string(kStaticScratchBytes >> 20) + " MiB) holds; use rt_render_device");
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }

@@ -57,4 +57,16 @@ hipError_t wavefront_traverse_time(WavefrontWorkspace& ws, double* ms_out, unsig
 // first frame rendered through it pays neither the allocation nor the first touch (rt_reserve).
 hipError_t wavefront_reserve(WavefrontWorkspace& ws, size_t rays_per_queue, int n_queues, hipStream_t stream);
 
+// The no-allocation variant (rt_render_device_noalloc): the workspace is carved out of a file-scope __device__ array of
+// kStaticScratchBytes in render_wavefront.hip.  wavefront_static_setup: once per device, with that device current
+// (rt_init): resolves the array's device address and pins the read-back words.  launch_render_wavefront_static: same
+// pixels as launch_render_wavefront through queues inside that array; hipErrorInvalidValue when the part is larger than
+// kStaticMaxPixels / kStaticMaxWidth, hipErrorOutOfMemory when the ray tree needs more queues than fit.
+constexpr size_t kStaticScratchBytes = size_t(64) << 20;
+constexpr int kStaticMaxPixels = 1 << 18;   // pixels of the rendered part (FP64 accumulators: 6 MiB of the array)
+constexpr int kStaticMaxWidth = 1024;       // an 8-row band of primary rays must fit the smallest queue
+hipError_t wavefront_static_setup(int device);
+hipError_t launch_render_wavefront_static(const DScene& scene, const DParams& params, uint8_t* d_rgb8, hipStream_t stream,
+                                          int device);
+
 }  // namespace rt

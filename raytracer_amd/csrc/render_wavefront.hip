@@ -1151,6 +1151,82 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ no-allocation variant
+// Callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it) get
+// the same wavefront render through a workspace carved out of this array: queue counters, statistics words, FP64
+// accumulators and as many ray queues as fit.  Every GPU the library runs on holds its own copy of the array at its
+// own address until the process ends; `scratch` itself is only the host-side stand-in of the symbol, so host code
+// resolves the address once per device (wavefront_static_setup, from rt_init) and uses that pointer everywhere.
+// All calls on a GPU share the array, which keeps the last call's contents: the driver clears what must start at zero
+// (counters, accumulators) on the caller's stream, and calls that overlap on one GPU race.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+unsigned* g_scratch_readback[kMaxDevices] = {};   // pinned host words for the queue-size read-backs of this variant
+constexpr size_t kStaticCountersOffset = 0;                       // (kNextBase + 256) unsigned words
+constexpr size_t kStaticStatsOffset = 4096;                       // RT_N_COUNTERS u64
+constexpr size_t kStaticAccumOffset = 8192;                       // kStaticMaxPixels x 3 doubles
+constexpr size_t kStaticQueuesOffset = kStaticAccumOffset + (size_t)kStaticMaxPixels * 3 * sizeof(double);
+static_assert((kNextBase + kXcds * kNextStride) * sizeof(unsigned) <= kStaticStatsOffset, "counters overlap the statistics words");
+static_assert(kStaticQueuesOffset % 256 == 0 && kStaticQueuesOffset < kStaticScratchBytes, "static scratch layout");
+}  // namespace
+
+hipError_t wavefront_static_setup(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // the current device's copy of the array
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    void* h = nullptr;
+    if ((e = hipHostMalloc(&h, 16 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess) return e;
+    g_scratch_readback[device] = static_cast<unsigned*>(h);
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    return hipSuccess;
+}
+
+hipError_t launch_render_wavefront_static(const DScene& scene, const DParams& params, uint8_t* d_rgb8, hipStream_t stream, int device) {
+    if (device < 0 || device >= kMaxDevices || !g_scratch_ptr[device]) return hipErrorNotInitialized;
+    const size_t npix = (size_t)params.part_rows * params.width;
+    if (npix == 0) return hipSuccess;
+    if (npix > (size_t)kStaticMaxPixels || params.width > kStaticMaxWidth) return hipErrorInvalidValue;
+    unsigned char* base = g_scratch_ptr[device];   // never `scratch`: that name is not a device address in host code
+    // As many queues as the ray tree is deep (one per level in flight, one being filled, one spare), as large as fits.
+    const size_t need = (size_t)tree_levels(scene, params) + 2;
+    const size_t room = kStaticScratchBytes - kStaticQueuesOffset;
+    size_t capacity = size_t(1) << 20;
+    while (capacity > 4096 && capacity * (sizeof(RayRec) + sizeof(HitRec)) * need > room) capacity >>= 1;
+    if ((size_t)params.width * 8 > capacity) return hipErrorInvalidValue;
+    const size_t n_queues = room / (capacity * (sizeof(RayRec) + sizeof(HitRec)));
+    WavefrontWorkspace ws;
+    ws.fixed = true;
+    ws.capacity = capacity;
+    ws.counters = reinterpret_cast<unsigned*>(base + kStaticCountersOffset);
+    ws.stats = reinterpret_cast<unsigned long long*>(base + kStaticStatsOffset);
+    ws.accum = reinterpret_cast<double*>(base + kStaticAccumOffset);
+    ws.accum_pixels = (size_t)kStaticMaxPixels;
+    ws.host_readback = g_scratch_readback[device];
+    unsigned char* q = base + kStaticQueuesOffset;
+    for (size_t i = 0; i < n_queues; ++i) {
+        ws.queues.push_back(q);
+        ws.hit_buffers.push_back(q + capacity * sizeof(RayRec));
+        ws.in_use.push_back(0);
+        q += capacity * (sizeof(RayRec) + sizeof(HitRec));
+    }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    ws.compute_units = cus;
+    ws.rays_per_lane = RT_RAYS_PER_LANE;
+    // the array keeps the previous call's contents: everything the kernels expect at zero is cleared on this stream
+    hipError_t e = hipMemsetAsync(base, 0, kStaticAccumOffset, stream);
+    if (e != hipSuccess) return e;
+    e = launch_render_wavefront(scene, params, d_rgb8, nullptr, stream, ws, nullptr);
+    // the workspace object dies here; its memory is the array's.  The frame's last kernels may still be running on `stream`.
+    return e;
+}
+
 hipError_t wavefront_traverse_time(WavefrontWorkspace& ws, double* ms_out, unsigned* launches_out) {
     double ms = 0.0;
     unsigned launches = 0;
