@@ -272,6 +272,7 @@ struct BuildClock {
 };
 
 // Builder of the hierarchy the device traverses: rt_set_bvh_builder(), else RT_BVH_BUILDER = sah | lbvh | median, else SAH.
+constexpr int kSmallScenePrimsHost = 16;     // == kSmallScenePrims of device_rt.h
 constexpr int kDeviceOrderMinShapes = 65536;   // below this the host passes (order, SAH tree) take a few milliseconds
 static int g_builder = -1;
 static int chosen_builder(int n_shapes = 0) {
@@ -485,6 +486,20 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     }
     sc->depth4 = b32.max_depth;
     sc->node_pad = b32.pad;
+    // Small scenes are rendered without the hierarchy (device_rt.h: closest_hit_small): each primitive's own box, widened
+    // like the node boxes, culls its FP64 test.
+    std::vector<float> prim_boxes;
+    if (desc->n_shapes > 0 && desc->n_shapes <= kSmallScenePrimsHost && sc->bvh.shape_boxes.size() == static_cast<size_t>(desc->n_shapes)) {
+        const double pad = b32.pad > 0.0 ? b32.pad : node4_pad(sc->bvh.root_box, max_camera_coordinate(*desc));
+        prim_boxes.resize(static_cast<size_t>(desc->n_shapes) * 6);
+        for (int k = 0; k < desc->n_shapes; ++k) {
+            const Box& b = sc->bvh.shape_boxes[sc->bvh.order[k]];
+            for (int a = 0; a < 3; ++a) {
+                prim_boxes[6 * k + a] = round_down(b.lo[a] - pad);
+                prim_boxes[6 * k + 3 + a] = round_up(b.hi[a] + pad);
+            }
+        }
+    }
     std::vector<Box>().swap(sc->bvh.shape_boxes);   // 48 bytes per shape the scene no longer needs
     HostArrays h = derive_arrays(*desc, sc->bvh);
     clock.lap("primitive arrays");
@@ -518,6 +533,9 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     }
     DTexture* d_tex;
     if ((rc = upload(tex, &d_tex))) return cleanup_fail(rc); track(d_tex);
+    float* d_pbox = nullptr;
+    if ((rc = upload(prim_boxes, &d_pbox))) return cleanup_fail(rc); track(d_pbox);
+    d.prim_boxes = d_pbox;
     float* d_env = nullptr;
     if (desc->env.present && desc->env.rgb && desc->env.width > 0) {
         size_t bytes = static_cast<size_t>(desc->env.width) * desc->env.height * 3 * sizeof(float);
@@ -534,6 +552,9 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     d.n_prims = desc->n_shapes;
     d.n_nodes = sc->n_nodes4;
     d.n_lights = desc->n_lights;
+    d.n_xforms = static_cast<int32_t>(h.xforms.size());
+    d.n_quads = static_cast<int32_t>(h.quads.size());
+    d.n_materials = desc->n_materials;
     d.root_ref = b32.root_ref;
     d.features = h.features;
     d.spawning_materials = h.spawning_materials;
@@ -651,6 +672,7 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     if (p->rng_mode != RT_RNG_D0 && p->rng_mode != RT_RNG_SEEDED) return fail(RT_ERR_INVALID, "unknown rng_mode");
     if (p->shadows && p->shadow_samples <= 0) return fail(RT_ERR_INVALID, "shadow_samples must be >= 1 when shadows are on");
     if (p->glossy_samples < 0) return fail(RT_ERR_INVALID, "glossy_samples must be >= 0");
+    if (p->glossy_samples > 60) return fail(RT_ERR_LIMIT, "glossy_samples is limited to 60 (one bit per reflection ray of a hit in the shading kernel)");
     if (p->schedule != RT_SCHEDULE_WAVEFRONT && p->schedule != RT_SCHEDULE_MEGAKERNEL) return fail(RT_ERR_INVALID, "unknown schedule");
     // Megakernel pending-ray stack bound: the first hit may queue glossy_samples + 1 rays, every deeper level at most one more.
     if (p->schedule == RT_SCHEDULE_MEGAKERNEL && std::max(p->max_depth, 0) + p->glossy_samples + 2 > kRayStackDepth)

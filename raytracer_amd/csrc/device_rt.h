@@ -64,20 +64,26 @@ struct Rng {
         return z ^ (z >> 31);
     }
     __device__ __forceinline__ double uniform() { return d0 ? 0.5 : (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
-    // random_utils.h:29-35 (rejection sampling of the unit ball)
+    // random_utils.h:29-35 (rejection sampling of the unit ball).  A wave repeats the loop until its unluckiest lane has
+    // accepted (6-8 rounds at 52 % acceptance), so a round is kept cheap: ONE draw gives the three coordinates, 21 bits
+    // each, tested in FP32 (the values are exact there); the distribution is the reference's up to that resolution.
     __device__ D3 in_unit_sphere() {
         if (d0) return mk(0, 0, 0);
-        for (int it = 0; it < 64; ++it) {  // acceptance 52 % per try; 64 tries leave 1e-21 of the mass
-            D3 p = mk(uniform() * 2 - 1, uniform() * 2 - 1, uniform() * 2 - 1);
-            if (dot(p, p) < 1.0) return p;
+        for (int it = 0; it < 64; ++it) {  // 64 tries leave 1e-21 of the mass
+            const unsigned long long z = next();
+            const float x = ((float)(unsigned)(z & 0x1FFFFFull) + 0.5f) * (1.0f / 1048576.0f) - 1.0f;
+            const float y = ((float)(unsigned)((z >> 21) & 0x1FFFFFull) + 0.5f) * (1.0f / 1048576.0f) - 1.0f;
+            const float w = ((float)(unsigned)((z >> 42) & 0x1FFFFFull) + 0.5f) * (1.0f / 1048576.0f) - 1.0f;
+            if (x * x + y * y + w * w < 1.0f) return mk((double)x, (double)y, (double)w);
         }
         return mk(0, 0, 0);
     }
-    // camera.cpp:13-24 (rejection sampling of the unit disk)
+    // camera.cpp:13-24 (rejection sampling of the unit disk; the reference's rand() has 31 bits, these have 32)
     __device__ D3 in_unit_disk() {
         if (d0) return mk(0, 0, 0);
         for (int it = 0; it < 64; ++it) {
-            D3 p = mk(uniform() * 2.0 - 1.0, uniform() * 2.0 - 1.0, 0.0);
+            const unsigned long long z = next();
+            D3 p = mk(((double)(unsigned)(z >> 32) + 0.5) * (1.0 / 2147483648.0) - 1.0, ((double)(unsigned)z + 0.5) * (1.0 / 2147483648.0) - 1.0, 0.0);
             if (dot(p, p) < 1.0) return p;
         }
         return mk(0, 0, 0);
@@ -558,6 +564,42 @@ __device__ __forceinline__ bool box_test32(const float* lo, const float* hi, con
     return tf >= tn;
 }
 
+// closest_hit_small: a primitive whose own (widened, FP32) box no lane's ray enters before its closest hit so far is
+// skipped by the whole wave -- the conservative slab test of the hierarchy's boxes, applied to the primitives directly.
+template <int F>
+__device__ __forceinline__ bool closest_hit_small(const DScene& S, const DParams& P, const Ray& r, double tmin, double tmax, Cand& best,
+                                                  Counters& C, bool any_hit, bool active = true) {
+    C.rays += active ? 1u : 0u;
+    best.t = tmax;
+    best.prim = -1;
+    best.tri = 0;
+    best.bu = best.bv = 0.0;
+    int best_order = 0;
+    bool best_incl = false;
+    bool live = active;
+    const RayF rf = make_rayf(r);
+    const float tmin32 = __double2float_rd(tmin);
+    float tmax32 = __double2float_ru(tmax);   // follows best.t (rounded up)
+    const int n = __builtin_amdgcn_readfirstlane(S.n_prims);
+    for (int i = 0; i < n; ++i) {
+        if (any_hit && __ballot(live) == 0ull) break;
+        const int prim = P.use_bvh ? i : __builtin_amdgcn_readfirstlane(S.file_order[i]);
+        bool enters = live;
+        if (S.prim_boxes) {
+            float e;
+            if (P.count_tests) C.nodes += live ? 1u : 0u;
+            enters = live && box_test32(S.prim_boxes + 6 * prim, S.prim_boxes + 6 * prim + 3, rf, tmin32, tmax32, e);
+        }
+        if (__ballot(enters) == 0ull) continue;
+        if (enters) {
+            test_prim<F>(S, P, r, prim, i, tmin, best, best_order, best_incl, C);
+            tmax32 = __double2float_ru(best.t);
+            if (any_hit && best.prim >= 0) live = false;
+        }
+    }
+    return best.prim >= 0;
+}
+
 // One 4-wide node (device_types.h: DNode4) pulled into registers with four 16-byte loads issued back to back.
 typedef unsigned rt_u4 __attribute__((ext_vector_type(4)));
 struct NodeRegs {
@@ -649,9 +691,11 @@ __device__ __forceinline__ int node4_children(const NodeRegs& n) {
 // Closest hit == `world.intersect(r, tmin, tmax, rec)` (hittable_list.cpp:8-33 over bvh.cpp:101-114).
 // Traversal is front-to-back with a per-lane stack of deferred children; the hit found equals the reference's
 // left-then-right recursion because closest-hit selection is order independent (ties: tie_new_wins).
+// any_hit: the caller only asks WHETHER something lies in (tmin, tmax) -- a shadow ray in a scene without transmitting
+// materials (shading.h:52-55: an opaque occluder gives 0 whichever it is) -- so the first hit found ends the traversal.
 template <int F>
 __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, double tmin, double tmax, Cand& best, Counters& C,
-                            TravStack& stack) {
+                            TravStack& stack, bool any_hit = false) {
     C.rays++;
     best.t = tmax;
     best.prim = -1;
@@ -661,7 +705,10 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
     bool best_incl = false;
     if (S.n_prims <= 0) return false;
     if (!P.use_bvh) {  // --no-bvh: the list in scene-file order
-        for (int i = 0; i < S.n_prims; ++i) test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+        for (int i = 0; i < S.n_prims; ++i) {
+            test_prim<F>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+            if (any_hit && best.prim >= 0) return true;
+        }
         return best.prim >= 0;
     }
     const RayF rf = make_rayf(r);
@@ -687,12 +734,72 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
             int first = code >> 1;
             test_prim<F>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
             if (code & 1) test_prim<F>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+            if (any_hit && best.prim >= 0) return true;
             tmax32 = __double2float_ru(best.t);
             cur = stack.pop(sp, tmax32);
         }
     }
     return best.prim >= 0;
 }
+
+// Scenes of a handful of primitives (the reference's own example scenes have 4 to 10): every lane of the wave tests
+// primitive 0, 1, 2 ... in step, so the primitive's record is the same for all lanes -- its loads are scalar, its type
+// switch is a scalar branch, nothing diverges and no hierarchy, stack or scheduling is involved.  Same closest hit as
+// the traversal (the tie rule makes the result independent of the testing order); `visit` maps step i to (primitive,
+// visit order) as the reference would meet them: the BVH's depth-first order, or the file order with --no-bvh.
+constexpr int kSmallScenePrims = 16;
+// (closest_hit_small itself stands with the box tests above)
+
+// The whole description of such a scene fits a few KB: the kernels for small scenes copy it into LDS once per workgroup
+// and hand the device functions a DScene whose arrays point there, so that the chains of dependent loads of a ray
+// (primitive -> transform -> material, light) cost LDS latency instead of an L2 round trip each.
+constexpr int kSmallSceneMaterials = 16, kSmallSceneLights = 8;
+struct SmallSceneLds {
+    float boxes[kSmallScenePrims * 6];
+    DPrim prims[kSmallScenePrims];
+    DXform xforms[kSmallScenePrims];
+    DQuad quads[kSmallScenePrims];
+    DMaterial materials[kSmallSceneMaterials];
+    DLight lights[kSmallSceneLights];
+};
+__device__ __forceinline__ void lds_copy_words(void* dst, const void* src, int bytes) {
+    unsigned* d = static_cast<unsigned*>(dst);
+    const unsigned* s = static_cast<const unsigned*>(src);
+    for (int i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
+}
+// Called by every thread of the workgroup (it contains a barrier); S.n_prims <= kSmallScenePrims is the caller's business.
+__device__ __forceinline__ DScene stage_small_scene(const DScene& S, SmallSceneLds& L) {
+    DScene T = S;
+    lds_copy_words(L.prims, S.prims, S.n_prims * (int)sizeof(DPrim));
+    lds_copy_words(L.xforms, S.xforms, S.n_xforms * (int)sizeof(DXform));
+    lds_copy_words(L.quads, S.quads, S.n_quads * (int)sizeof(DQuad));
+    T.prims = L.prims;
+    T.xforms = L.xforms;
+    T.quads = L.quads;
+    if (S.prim_boxes) {
+        lds_copy_words(L.boxes, S.prim_boxes, S.n_prims * 6 * (int)sizeof(float));
+        T.prim_boxes = L.boxes;
+    }
+    if (S.n_materials <= kSmallSceneMaterials) {
+        lds_copy_words(L.materials, S.materials, S.n_materials * (int)sizeof(DMaterial));
+        T.materials = L.materials;
+    }
+    if (S.n_lights <= kSmallSceneLights) {
+        lds_copy_words(L.lights, S.lights, S.n_lights * (int)sizeof(DLight));
+        T.lights = L.lights;
+    }
+    __syncthreads();
+    return T;
+}
+
+template <bool SMALL> struct SceneStage;
+template <> struct SceneStage<true> {
+    SmallSceneLds lds;
+    __device__ __forceinline__ DScene stage(const DScene& S) { return stage_small_scene(S, lds); }
+};
+template <> struct SceneStage<false> {
+    __device__ __forceinline__ DScene stage(const DScene& S) { return S; }
+};
 
 // ------------------------------------------------------------------------------------------ hit record
 struct Hit {

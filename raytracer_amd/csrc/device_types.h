@@ -128,9 +128,12 @@ struct DScene {
     const DMaterial* materials;
     const DTexture* textures;
     const DLight* lights;
+    const float* prim_boxes;      // scenes of at most kSmallScenePrims primitives: world box of primitive k, widened like the node
+                                  // boxes, as lo xyz, hi xyz (FP32); else null
     const float* env;             // float RGB rows in file order, may be null
     int32_t env_present, env_w, env_h;
     int32_t n_prims, n_nodes, n_lights;
+    int32_t n_xforms, n_quads, n_materials;
     int32_t root_ref;             // reference to the root (node 0 or a leaf)
     int32_t features;             // RT_FEAT_* bits: which code paths this scene can reach
     float root_lo[3], root_hi[3];   // widened like the node boxes

@@ -23,6 +23,7 @@ struct WavefrontWorkspace {
     std::vector<void*> queues;           // RayRec[capacity] each
     std::vector<void*> hit_buffers;      // HitRec[capacity] each, paired with queues
     std::vector<char> in_use;
+    void* bundles = nullptr;             // shadow bundles of one shading launch: capacity x 128 bytes (allocated with the first frame that has shadows)
     double* accum = nullptr;             // FP64 RGB accumulator per pixel of the part
     size_t accum_pixels = 0;
     unsigned* counters = nullptr;        // [0] next ray to fetch, [1] rays emitted, [2] overflow flag

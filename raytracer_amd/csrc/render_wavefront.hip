@@ -107,15 +107,57 @@ __device__ __forceinline__ void hit_store(const HitQ q, unsigned i, const HitRec
     q.p[(size_t)q.stride + i] = b.v[1];
 }
 
+// Shadow rays do not travel through the ray queues.  A radiance hit writes ONE bundle per light -- what its
+// 2 x shadow_samples shadow rays have in common (shading.h:79-101 evaluated for the diffuse and for the specular term,
+// shading.h:154,192) -- and k_shadow traces the bundle's rays with one lane each: 128 bytes per (hit, light) instead of
+// 2 x samples x (112-byte ray + 32-byte hit record), written once and read by neighbouring lanes.
+struct alignas(16) Bundle {
+    double p[3];       // the shaded point: directions and distances run from here (shading.h:86-90)
+    double org[3];     // ray origin p + n * eps (shading.h:93)
+    double wd[3];      // what one ray of the diffuse evaluation adds to the pixel when it reaches the light
+    double ws[3];      // ... of the specular evaluation
+    double time;
+    unsigned long long rng;
+    int pixel, light;
+    int depth, pad;
+};
+static_assert(sizeof(Bundle) == 128, "Bundle size");
+struct BundleQ {
+    rt_q4* p;
+    unsigned stride;
+};
+union BundleBits {
+    Bundle b;
+    rt_q4 v[8];
+    __device__ BundleBits() {}
+};
+__device__ __forceinline__ Bundle bundle_load(const BundleQ q, unsigned i) {
+    BundleBits b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    return b.b;
+}
+__device__ __forceinline__ void bundle_store(const BundleQ q, unsigned i, const Bundle& v) {
+    BundleBits b;
+    b.b = v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
+}
+
 struct Chunk {
     int row0, rows;     // compact rows [row0, row0 + rows) of this part
     int s0, ns;         // samples [s0, s0 + ns) of every pixel
 };
 
-__device__ __forceinline__ void accum_add(double* accum, int pixel, D3 c) {
-    unsafeAtomicAdd(&accum[pixel * 3 + 0], c.x);
-    unsafeAtomicAdd(&accum[pixel * 3 + 1], c.y);
-    unsafeAtomicAdd(&accum[pixel * 3 + 2], c.z);
+// The accumulators are three planes (all reds, all greens, all blues of the part): float atomics execute at the memory
+// side as 64-byte requests (MI355X_MICROARCH.md, global float atomics), so what an atomic instruction costs is the number
+// of 64-byte segments its lanes touch; neighbouring lanes hold neighbouring pixels, and a plane puts their 8-byte sums
+// side by side (8 pixels per request) where interleaved RGB spreads them over three times as many segments.
+__device__ __forceinline__ void accum_add(double* accum, const DParams& P, int pixel, D3 c) {
+    const size_t plane = (size_t)P.part_rows * P.width;
+    unsafeAtomicAdd(&accum[pixel], c.x);
+    unsafeAtomicAdd(&accum[plane + pixel], c.y);
+    unsafeAtomicAdd(&accum[2 * plane + pixel], c.z);
 }
 
 // Reserve one output slot for every lane that calls this (wave-aggregated: one atomic per wave and call site).
@@ -154,24 +196,6 @@ __device__ __forceinline__ unsigned emit_reserve(unsigned* count, unsigned per_l
     if (lane == leader) base = atomicAdd(count, lanes * per_lane);
     base = __shfl(base, leader);
     return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-}
-// emit_reserve_counted: lane-dependent counts; this lane's rays go to [first, first + mine).
-__device__ __forceinline__ unsigned emit_reserve_counted(unsigned* count, unsigned mine) {
-    const unsigned long long m = __ballot(1);
-    const int lane = threadIdx.x & 63;
-    // counts are small and this runs once per reflecting hit: walk the calling lanes in order (uniform loop over m)
-    unsigned before = 0, total = 0;
-    for (unsigned long long rest = m; rest != 0ull; rest &= rest - 1ull) {
-        const int src = __ffsll((long long)rest) - 1;
-        const unsigned c = __shfl(mine, src);
-        if (src < lane) before += c;
-        total += c;
-    }
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(count, total);
-    base = __shfl(base, leader);
-    return base + before;
 }
 __device__ __forceinline__ void emit_ray_at(const RayQ out, unsigned slot, unsigned cap, unsigned* overflow, D3 o, D3 d, D3 w, double time,
                                             double tmax, unsigned long long rng, int pixel, int depth, int kind) {
@@ -261,6 +285,7 @@ constexpr unsigned kXcds = 8;
 constexpr unsigned kNextStride = kFetchCounterWords / kXcds;   // counters 128 bytes apart
 constexpr unsigned kNextBase = 32;     // offset of the fetch counters in WavefrontWorkspace::counters
 constexpr unsigned kLevelCountBase = 4;   // two queue-size words of the levels enqueued without a host round trip
+constexpr unsigned kBundleCount = 3;      // shadow bundles written by the current shading launch
 __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
     return q >= kXcds ? n : (unsigned)(((unsigned long long)n * q / kXcds) & ~63ull);
 }
@@ -440,6 +465,9 @@ struct EmitCtx {
     unsigned cap;
     uint8_t* direct;   // non-null: one ray per pixel and no children (1 spp, nothing spawns rays): the colour of a ray is
                        // the pixel, written tone-mapped straight into the frame instead of summed and resolved later
+    BundleQ bundles;   // shadow bundles of this launch's hits (k_shadow traces them), their count, the buffer's capacity
+    unsigned* bundle_count;
+    unsigned bundle_cap;
 };
 
 // Contribution c of one ray to its pixel.
@@ -451,7 +479,7 @@ __device__ __forceinline__ void deposit(const EmitCtx& E, const DParams& P, doub
         o[1] = quantise(m.y);
         o[2] = quantise(m.z);
     } else {
-        accum_add(accum, pixel, c);
+        accum_add(accum, P, pixel, c);
     }
 }
 
@@ -556,14 +584,10 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     const D3 V = normalize(r.o - Pt);
     D3 ad = cmul(cmul(ld3(M.ambient), ld3(P.ambient_light)), base);
     D3 spec = mk(0, 0, 0);
-    // The queue's tail is one word and every returning atomic on it is a round trip the wave waits for (shading-heavy
-    // frames spend 4/5 of their wave cycles waiting): the slots of the shadow rays of ALL lights of a hit are reserved
-    // with one atomic per wave, and those of all other children with a second one below.
-    unsigned shadow_lanes = 0, shadow_first = 0, shadow_j = 0;
-    if (EMIT && P.shadows && S.n_lights > 0) {
-        const unsigned per_hit = 2u * (unsigned)S.n_lights * (unsigned)P.shadow_samples;
-        shadow_first = emit_reserve(E.count, per_hit, shadow_lanes);
-    }
+    // With shadows every light's terms reach the pixel through its shadow rays: one bundle per (hit, light), slots for all
+    // lights of the hit reserved with one atomic per wave.
+    unsigned bundle_lanes = 0, bundle_first = 0;
+    if (EMIT && P.shadows && S.n_lights > 0) bundle_first = emit_reserve(E.bundle_count, (unsigned)S.n_lights, bundle_lanes);
     for (int li = 0; li < S.n_lights; ++li) {
         const DLight& L = S.lights[li];
         D3 Lr = ld3(L.pos) - Pt;
@@ -583,33 +607,17 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
             // compute_light_visibility (shading.h:79-101) is evaluated once for the diffuse and once for the specular
             // term (shading.h:154,192), shadow_samples rays each; a ray that reaches the light adds weight/samples.
             const double inv_s = 1.0 / P.shadow_samples;
+            const unsigned slot = bundle_first + (unsigned)li * bundle_lanes;
+            if (slot >= E.bundle_cap) { *E.overflow = 1u; continue; }   // the host sizes batches so that this cannot happen
+            Bundle b;
             const D3 org = Pt + N * P.eps_shadow;
-            // a point light (radius 0, shading.h:33) has one sample point: direction and distance of its 2 x samples rays
-            // are the same numbers, computed once instead of per ray (a square root and four divisions each)
-            const bool point_light = L.radius == 0.0;
-            D3 d_point = mk(0, 0, 0);
-            double dist_point = 0.0;
-            if (point_light) {
-                const D3 dd = ld3(L.pos) - Pt;
-                dist_point = length(dd);
-                d_point = normalize(dd);
-            }
-            for (int pass = 0; pass < 2; ++pass) {
-                const D3 wt = (pass == 0) ? cmul(w, diff * ad_weight) * inv_s : cmul(w, sp) * inv_s;
-                for (int k = 0; k < P.shadow_samples; ++k) {
-                    D3 d = d_point;
-                    double dist = dist_point;
-                    if (!point_light) {
-                        const D3 lp = ld3(L.pos) + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
-                        d = lp - Pt;
-                        dist = length(d);
-                        d = normalize(d);
-                    }
-                    emit_ray_at(E.out, shadow_first + shadow_j * shadow_lanes, E.cap, E.overflow, org, d, wt, q.time, dist, rng.next(), q.pixel, q.depth,
-                                kKindShadow);
-                    ++shadow_j;
-                }
-            }
+            const D3 wdv = cmul(w, diff * ad_weight) * inv_s, wsv = cmul(w, sp) * inv_s;
+            b.p[0] = Pt.x; b.p[1] = Pt.y; b.p[2] = Pt.z;
+            b.org[0] = org.x; b.org[1] = org.y; b.org[2] = org.z;
+            b.wd[0] = wdv.x; b.wd[1] = wdv.y; b.wd[2] = wdv.z;
+            b.ws[0] = wsv.x; b.ws[1] = wsv.y; b.ws[2] = wsv.z;
+            b.time = q.time; b.rng = rng.next(); b.pixel = q.pixel; b.light = li; b.depth = q.depth; b.pad = 0;
+            bundle_store(E.bundles, slot, b);
         }
     }
     contrib = cmul(w, ad * ad_weight + spec);
@@ -618,12 +626,15 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     if (!EMIT) return true;
     const int child_depth = q.depth - 1;
     if (child_depth <= 0) return true;  // children would return black without tracing (tracer.h:149)
-    // reflection (tracer.h:176-219): samples below the surface are dropped (tracer.h:196-204), so the kept ones are counted
-    // first with a copy of the random stream; then all children of this hit get their slots with one atomic per wave
+    // reflection (tracer.h:176-219): samples below the surface are dropped (tracer.h:196-204), so the kept ones are found
+    // first with a copy of the random stream.  All children of the wave's hits then get their slots with one atomic,
+    // SAMPLE-major: the lanes that keep sample k take consecutive slots, so every store instruction of the wave writes
+    // consecutive 16-byte pieces (a lane's own rays side by side would put the lanes of an instruction 128 bytes and more
+    // apart, and the L2 passes such pieces on to memory one by one: measured, 6 x the bytes).
     int samples = 0;
     double rough = 0.0;
     D3 perfect = mk(0, 0, 0), wr = mk(0, 0, 0), org = mk(0, 0, 0);
-    unsigned mine = 0;
+    unsigned long long keep = 0ull;   // bit k < 62: reflection ray k of this hit; bit 62: TIR mirror ray; bit 63: refraction ray
     if (has_refl) {
         samples = P.glossy_samples;
         if (q.depth < P.max_bounces) samples = 1;
@@ -639,33 +650,51 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
             for (int k = 0; k < samples; ++k) {
                 D3 off = dry.in_unit_sphere() * rough;
                 D3 target = normalize(perfect + off);
-                if (dot(target, h.n) > 0) { ++mine; (void)dry.next(); }
+                if (dot(target, h.n) > 0) { keep |= 1ull << k; (void)dry.next(); }
             }
         } else {
-            mine = 1;
+            keep = 1ull;
         }
     }
-    if (tir_mirror) ++mine;
-    if (do_refract) ++mine;
-    unsigned slot = emit_reserve_counted(E.count, mine);
-    if (has_refl) {
-        if (samples > 0) {
-            for (int k = 0; k < samples; ++k) {
+    if (tir_mirror) keep |= 1ull << 62;
+    if (do_refract) keep |= 1ull << 63;
+    // how many rays the lanes of the wave that got here emit (ballots count only them), and one atomic for all
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int kmax = has_refl ? (samples > 0 ? samples : 1) : 0;   // reflection slots of this lane
+    unsigned total = (unsigned)__popcll(__ballot(tir_mirror)) + (unsigned)__popcll(__ballot(do_refract));
+    for (int k = 0; __ballot(k < kmax) != 0ull; ++k) total += (unsigned)__popcll(__ballot((keep >> k) & 1ull));
+    const int leader = __ffsll((long long)__ballot(1)) - 1;
+    unsigned slot0 = 0;
+    if (lane == leader && total != 0u) slot0 = atomicAdd(E.count, total);
+    slot0 = __shfl(slot0, leader);
+    for (int k = 0; __ballot(k < kmax) != 0ull; ++k) {
+        const unsigned long long mk_ = __ballot((keep >> k) & 1ull);
+        if (k < kmax) {
+            D3 target = perfect;
+            bool mine_k = true;
+            if (samples > 0) {
                 D3 off = rng.in_unit_sphere() * rough;
-                D3 target = normalize(perfect + off);
-                if (dot(target, h.n) > 0)
-                    emit_ray_at(E.out, slot++, E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+                target = normalize(perfect + off);
+                mine_k = dot(target, h.n) > 0;
             }
-        } else {
-            emit_ray_at(E.out, slot++, E.cap, E.overflow, org, perfect, wr, q.time, 100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+            if (mine_k)
+                emit_ray_at(E.out, slot0 + (unsigned)__popcll(mk_ & below), E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel,
+                            child_depth, kKindRadiance);
         }
+        slot0 += (unsigned)__popcll(mk_);
     }
-    if (tir_mirror)  // tracer.h:258-264 (not tinted for metals)
-        emit_ray_at(E.out, slot++, E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time, 100000.0,
-                    rng.next(), q.pixel, child_depth, kKindRadiance);
-    if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
-        emit_ray_at(E.out, slot++, E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time, 100000.0,
-                    rng.next(), q.pixel, child_depth, kKindRadiance);
+    {
+        const unsigned long long mt = __ballot(tir_mirror);
+        if (tir_mirror)  // tracer.h:258-264 (not tinted for metals)
+            emit_ray_at(E.out, slot0 + (unsigned)__popcll(mt & below), E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time,
+                        100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+        slot0 += (unsigned)__popcll(mt);
+        const unsigned long long mr = __ballot(do_refract);
+        if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
+            emit_ray_at(E.out, slot0 + (unsigned)__popcll(mr & below), E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time,
+                        100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
+    }
     return true;
 }
 
@@ -676,12 +705,14 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 1          // waves per SIMD asked of the register allocator for the shading kernel
 #endif
-template <int F, bool EMIT>
-__global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S, const DParams P, const RayQ rays,
+template <int F, bool EMIT, bool SMALL>
+__global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays,
                                                   const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
                                                   const EmitCtx E, double* __restrict__ accum) {
+    __shared__ SceneStage<SMALL> staged;
     const unsigned n = n_device ? min(*n_device, n_host) : n_host;   // see k_traverse; the grid covers n_host
     if (blockIdx.x * kBlock >= n) return;
+    const DScene S = staged.stage(S0);
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     D3 c = mk(0.0, 0.0, 0.0);
@@ -709,7 +740,178 @@ __global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S
         const double ox = __shfl_down(c.x, d), oy = __shfl_down(c.y, d), oz = __shfl_down(c.z, d);
         if (lane + d <= run_end) { c.x += ox; c.y += oy; c.z += oz; }
     }
-    if (pixel >= 0 && ((heads >> lane) & 1ull)) accum_add(accum, pixel, c);
+    if (pixel >= 0 && ((heads >> lane) & 1ull)) accum_add(accum, P, pixel, c);
+}
+
+// ------------------------------------------------------------------------------------------ k_shadow
+// One lane per shadow ray: lane i traces ray i % (2 x samples) of bundle i / (2 x samples) -- the first `samples` rays
+// belong to the diffuse evaluation of the light's visibility, the others to the specular one (shading.h:154,192) -- from
+// the light sample (shading.h:31-36) through every transmitting occluder (shading.h:42-75) to the light, inside this
+// kernel: no queue entry, no hit record, no second kernel.  The rays of a bundle are neighbouring lanes with the same
+// pixel, bundles of one hit and of neighbouring samples of a pixel follow each other, so the wave sums runs of equal
+// pixel before the FP64 atomics (as k_shade does).  A chain longer than kInlineSegments segments goes on as an
+// ordinary shadow ray of the next level's queue (shade_ray continues it there).
+constexpr int kInlineSegments = 6;
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 3         // waves per SIMD asked of the register allocator: 3 measured 5-8 % faster than 2 on the analytic
+#endif                            // variants; the variant with the ray marcher and the texture paths spills at that budget (x 1.6)
+template <int F, bool SMALL>
+__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? 2 : RT_SHADOW_WAVES)
+k_shadow(const DScene S0, const DParams P, const BundleQ bundles, const unsigned* __restrict__ n_bundles, const unsigned cap,
+         const EmitCtx E, double* __restrict__ accum, unsigned long long* __restrict__ stats) {
+    __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
+    __shared__ SceneStage<SMALL> staged;
+    const DScene S = staged.stage(S0);
+    const unsigned per = 2u * (unsigned)P.shadow_samples;
+    const unsigned long long n = (unsigned long long)min(*n_bundles, cap) * per;
+    const int lane = threadIdx.x & 63;
+    TravStack stack;
+    stack.lds = &stack_mem[0][threadIdx.x];
+    stack.stride = kBlock;
+    Counters C{0u, 0u, 0u, 0u};
+    const bool any_hit = S.transparent_materials == 0;
+    // the grid is sized by the machine, not by the bound on the bundles (most levels of a ray tree hold far fewer than
+    // the bound): every workgroup strides over the rays that are really there
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < n; base += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long i = base + threadIdx.x;
+        D3 c = mk(0.0, 0.0, 0.0);
+        int pixel = -1 - lane;
+        const bool mine = i < n;
+        Bundle b;
+        Ray sr{mk(0, 0, 0), mk(0, 0, 1), 0.0};
+        D3 wt = mk(0, 0, 0);
+        double dist = 0.0;
+        Rng rng{0ull, true};
+        if (mine) {
+            const unsigned bi = (unsigned)(i / per), k = (unsigned)(i % per);
+            b = bundle_load(bundles, bi);
+            const DLight& L = S.lights[b.light];
+            const bool specular = k >= (unsigned)P.shadow_samples;
+            // this ray's own random stream (the reference draws the samples of a hit one after the other from one
+            // generator; the estimator only needs them independent)
+            rng = Rng{b.rng ^ ((unsigned long long)(k + 1u) * 0xD1B54A32D192ED03ull), P.rng_mode == RT_RNG_D0};
+            (void)rng.next();
+            const D3 Pt = ld3(b.p);
+            D3 lp = ld3(L.pos);
+            if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
+            D3 d = lp - Pt;
+            dist = length(d);
+            d = normalize(d);
+            sr = Ray{ld3(b.org), d, b.time};
+            wt = specular ? ld3(b.ws) : ld3(b.wd);
+        }
+        bool going = mine, reached = false;
+        int seg = 0;
+        for (; seg < kInlineSegments; ++seg) {
+            if (SMALL) { if (__ballot(going) == 0ull) break; }
+            else if (!going) break;
+            Cand cand;
+            const bool hit = SMALL ? closest_hit_small<F>(S, P, sr, 0.001, dist - 0.001, cand, C, any_hit, going)
+                                   : closest_hit<F>(S, P, sr, 0.001, dist - 0.001, cand, C, stack, any_hit);
+            if (!going) continue;
+            if (!hit) { reached = true; going = false; continue; }
+            const DPrim pr = S.prims[cand.prim];
+            const DMaterial& M = S.materials[pr.material];
+            if (!(M.transparency > 0.0)) { going = false; continue; }  // opaque occluder: transmission 0
+            Hit h;
+            fill_hit<F>(S, P, sr, cand, h);
+            double n1 = h.front ? 1.0 : M.ior, n2 = h.front ? M.ior : 1.0;
+            double eta = n1 / n2;
+            double cos_i = -dot(sr.d, h.n);
+            double sin2 = eta * eta * (1.0 - cos_i * cos_i);
+            if (sin2 > 1.0) { going = false; continue; }
+            double r0 = ((n1 - n2) / (n1 + n2));
+            r0 = r0 * r0;
+            double refl = r0 + (1.0 - r0) * pow((1.0 - cos_i), 5.0);  // shadow_schlick, shading.h:24-28
+            D3 local = cmul(mk(1.0, 1.0, 1.0), ld3(M.diffuse)) * (1.0 - refl);
+            if (length(local) < 0.001) { going = false; continue; }
+            wt = cmul(wt, local);
+            sr.o = h.p + sr.d * 0.001;
+            dist = dist - h.t;
+        }
+        if (reached) {
+            c = wt;
+            pixel = b.pixel;
+        } else if (going) {   // still inside a stack of transmitting surfaces: the next level's queue takes over
+            emit_ray(E.out, E.count, E.cap, E.overflow, sr.o, sr.d, wt, b.time, dist, rng.next(), b.pixel, b.depth, kKindShadow);
+        }
+        const int left = __shfl_up(pixel, 1);
+        const unsigned long long heads = __ballot(lane == 0 || left != pixel);
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int run_end = above ? lane + __ffsll((long long)above) - 1 : 63;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const double ox = __shfl_down(c.x, dlt), oy = __shfl_down(c.y, dlt), oz = __shfl_down(c.z, dlt);
+            if (lane + dlt <= run_end) { c.x += ox; c.y += oy; c.z += oz; }
+        }
+        if (pixel >= 0 && ((heads >> lane) & 1ull)) accum_add(accum, P, pixel, c);
+    }
+    // closest-hit queries of this wave (== the reference's world.intersect calls of its shadow rays)
+    unsigned rays = C.rays, nodes = C.nodes, prims = C.prims, visits = C.visits;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off);
+        if (P.count_tests) {
+            nodes += __shfl_down(nodes, off);
+            prims += __shfl_down(prims, off);
+            visits += __shfl_down(visits, off);
+        }
+    }
+    if (lane == 0 && rays != 0u) {
+        atomicAdd(&stats[7], (unsigned long long)rays);
+        if (P.count_tests) {
+            atomicAdd(&stats[1], (unsigned long long)nodes);
+            atomicAdd(&stats[2], (unsigned long long)prims);
+            atomicAdd(&stats[4], (unsigned long long)visits);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ k_traverse_small
+// k_traverse for scenes of at most kSmallScenePrims primitives: one lane per queued ray, every primitive tested in step
+// by the whole wave (closest_hit_small).  The persistent scheduling of k_traverse -- refill, votes, parked leaves, a
+// stack -- buys nothing when there is no hierarchy to speak of, and costs most of the time of such frames.
+template <int F>
+__global__ void __launch_bounds__(kBlock, 4)
+k_traverse_small(const DScene S0, const DParams P, const RayQ rays, const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
+                 unsigned long long* __restrict__ counters) {
+    __shared__ SmallSceneLds small_lds;
+    const unsigned n = n_device ? min(*n_device, n_host) : n_host;
+    if (blockIdx.x * kBlock >= n) return;   // (whole workgroup: before the barrier of the staging)
+    const DScene S = stage_small_scene(S0, small_lds);
+    if (n_device && blockIdx.x == 0 && threadIdx.x == 0 && n != 0u) atomicAdd(&counters[0], (unsigned long long)n);
+    const int lane = threadIdx.x & 63;
+    Counters C{0u, 0u, 0u, 0u};
+    for (unsigned base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const unsigned i = base + threadIdx.x;
+        const bool mine = i < n;
+        Ray r{mk(0, 0, 0), mk(0, 0, 1), 0.0};
+        double tmin = 0.0, tmax = 0.0;
+        bool shadow = false;
+        if (mine) {
+            const RayRec q = ray_load(rays, i);
+            r.o = ld3(q.o);
+            r.d = ld3(q.d);
+            r.time = q.time;
+            shadow = q.kind == kKindShadow;
+            tmin = shadow ? 0.001 : P.eps_scene;                 // shading.h:45 / tracer.h:152-156
+            tmax = shadow ? q.tmax - 0.001 : q.tmax;
+        }
+        Cand best;
+        // queued shadow rays are continuations through transmitting surfaces: they need their closest occluder
+        (void)closest_hit_small<F>(S, P, r, tmin, tmax, best, C, false, mine);
+        if (mine) {
+            HitRec h;
+            h.t = best.t; h.bu = best.bu; h.bv = best.bv; h.prim = best.prim; h.tri = best.tri;
+            hit_store(hits, i, h);
+        }
+    }
+    if (P.count_tests && counters) {
+        unsigned prims = C.prims;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) prims += __shfl_down(prims, off);
+        if (lane == 0 && prims != 0u) atomicAdd(&counters[2], (unsigned long long)prims);   // (idle waves of a nearly empty level stay off the counter)
+    }
 }
 
 // ------------------------------------------------------------------------------------------ k_resolve
@@ -717,7 +919,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ a
                                                     const int spp, const int mode) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= npix) return;
-    D3 c = mk(accum[i * 3 + 0], accum[i * 3 + 1], accum[i * 3 + 2]);
+    D3 c = mk(accum[i], accum[(size_t)npix + i], accum[2 * (size_t)npix + i]);
     D3 avg = tonemap(c * (1.0 / spp), mode);  // main.cpp:308-316
     out[i * 3 + 0] = quantise(avg.x);
     out[i * 3 + 1] = quantise(avg.y);
@@ -726,9 +928,10 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ a
 
 __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, unsigned long long boxes, unsigned long long prims,
                                unsigned long long traverse_ns, unsigned long long fetches, unsigned long long max_fetches,
-                               unsigned long long max_iters) {
+                               unsigned long long max_iters, const unsigned long long* __restrict__ shadow_rays) {
     if (threadIdx.x == 0) {
-        c[0] += rays; c[1] += boxes; c[2] += prims; c[3] += traverse_ns; c[4] += fetches;
+        c[0] += rays + (shadow_rays ? *shadow_rays : 0ull);   // queue entries traversed (host count) + rays traced inside k_shadow
+        c[1] += boxes; c[2] += prims; c[3] += traverse_ns; c[4] += fetches;
         if (max_fetches > c[5]) c[5] = max_fetches;
         if (max_iters > c[6]) c[6] = max_iters;
     }
@@ -737,8 +940,8 @@ __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, u
 // Linear radiance (the average before tone mapping) for float output and progressive accumulation.
 __global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const int n3,
                                                            const int spp) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n3) out[i] = accum[i] * (1.0 / spp);
+    const int i = blockIdx.x * kBlock + threadIdx.x;   // interleaved RGB out, planes in
+    if (i < n3) out[i] = accum[(size_t)(i % 3) * (size_t)(n3 / 3) + i / 3] * (1.0 / spp);
 }
 
 // ------------------------------------------------------------------------------------------ host driver
@@ -811,6 +1014,11 @@ struct Driver {
         else if (e0) --ws.events_used;   // keep start/stop pairs whole
     }
     template <int F> void launch_traverse_kernel(int q, unsigned n, const unsigned* n_device) {
+        if (small_scene()) {
+            const unsigned blocks = std::max(1u, std::min((n + kBlock - 1) / kBlock, (unsigned)ws.compute_units * 16u));
+            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, ws.stats);
+            return;
+        }
         // Persistent grid sized by the work: at least RT_RAYS_PER_LANE rays per lane, so that lanes can be refilled and
         // a small queue (a part of a frame, a deep level of the ray tree) leaves the other CUs to concurrent streams.
         const unsigned per_block = kBlock * (unsigned)std::max(1, ws.rays_per_lane);
@@ -823,15 +1031,44 @@ struct Driver {
             hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
                                ws.counters + kNextBase, ws.stats);
     }
+    bool with_shadows() const { return may_emit && P.shadows && S.n_lights > 0; }
+    bool small_scene() const { return S.n_prims <= kSmallScenePrims && getenv("RT_NO_SMALL_SCENE") == nullptr; }
+    EmitCtx emit_ctx(int qo, unsigned* count) {
+        return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, count ? count : ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct,
+                       BundleQ{static_cast<rt_q4*>(ws.bundles), (unsigned)ws.capacity}, ws.counters + kBundleCount,
+                       ws.bundles ? (unsigned)ws.capacity : 0u};
+    }
+    // The shadow rays of the hits a shading launch of n rays has just bundled (at most n x lights bundles, never more than the buffer holds).
+    template <int F> void launch_shadow(unsigned n, int qo, unsigned* count) {
+        const EmitCtx E = emit_ctx(qo, count);
+        const unsigned long long bound = std::min<unsigned long long>((unsigned long long)n * (unsigned)S.n_lights, ws.capacity) * 2ull * (unsigned)P.shadow_samples;
+        const unsigned long long blocks = std::min<unsigned long long>((bound + kBlock - 1) / kBlock, (unsigned long long)ws.compute_units * 16ull);
+        if (blocks == 0) return;
+        if (small_scene())
+            hipLaunchKernelGGL((k_shadow<F, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, S, P, E.bundles, ws.counters + kBundleCount, E.bundle_cap, E,
+                               ws.accum, ws.stats);
+        else
+            hipLaunchKernelGGL((k_shadow<F, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, S, P, E.bundles, ws.counters + kBundleCount, E.bundle_cap, E,
+                               ws.accum, ws.stats);
+    }
+    void shadow(unsigned n, int qo, unsigned* count = nullptr) {
+        if (!with_shadows()) return;
+        if (variant == 0) launch_shadow<kSpheres>(n, qo, count);
+        else if (variant == 1) launch_shadow<kAnalytic>(n, qo, count);
+        else launch_shadow<kFull>(n, qo, count);
+    }
     template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr,
                                        unsigned* count = nullptr) {
-        EmitCtx E{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, count ? count : ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct};
-        if (may_emit)
-            hipLaunchKernelGGL((k_shade<F, true>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
-                               n_device, E, ws.accum);
+        const EmitCtx E = emit_ctx(qo, count);
+        const dim3 grid((n + kBlock - 1) / kBlock);
+        if (may_emit && small_scene())
+            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
+        else if (may_emit)
+            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
+        else if (small_scene())
+            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
         else
-            hipLaunchKernelGGL((k_shade<F, false>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n,
-                               n_device, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
     }
     void traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
         if (variant == 0) launch_traverse<kSpheres>(q, n, n_device);
@@ -866,7 +1103,9 @@ struct Driver {
             if (qo < 0) break;
             unsigned* out_count = cnt + ((level + 1) & 1);
             if (!ok(hipMemsetAsync(out_count, 0, sizeof(unsigned), stream))) { release(qo); break; }
+            if (with_shadows() && !ok(hipMemsetAsync(ws.counters + kBundleCount, 0, sizeof(unsigned), stream))) { release(qo); break; }
             shade(q, 0, n, qo, n_dev, out_count);
+            shadow(n, qo, out_count);
             release(q);   // stream order: whatever reuses these buffers runs after this level's kernels
             q = qo;
             bound = std::min<size_t>(ws.capacity, bound * fanout(level));
@@ -924,8 +1163,9 @@ struct Driver {
             const unsigned m = std::min(batch, n - start);
             const int qo = acquire();
             if (qo < 0) break;
-            if (!ok(hipMemsetAsync(ws.counters + 1, 0, 2 * sizeof(unsigned), stream))) { release(qo); break; }
+            if (!ok(hipMemsetAsync(ws.counters + 1, 0, 3 * sizeof(unsigned), stream))) { release(qo); break; }   // emitted, overflow, bundles
             shade(q, start, m, qo);
+            shadow(m, qo);
             unsigned local[2] = {0, 0};
             unsigned* res = ws.host_readback ? ws.host_readback : local;
             if (!ok(hipMemcpyAsync(res, ws.counters + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
@@ -947,6 +1187,7 @@ void wavefront_workspace_free(WavefrontWorkspace& ws) {
     if (!ws.fixed) {
         for (void* p : ws.queues) (void)hipFree(p);
         for (void* p : ws.hit_buffers) (void)hipFree(p);
+        if (ws.bundles) (void)hipFree(ws.bundles);
         if (ws.accum) (void)hipFree(ws.accum);
         if (ws.counters) (void)hipFree(ws.counters);
         if (ws.stats) (void)hipFree(ws.stats);
@@ -976,6 +1217,8 @@ hipError_t drop_queues(WavefrontWorkspace& ws, hipStream_t stream) {
     if (e != hipSuccess) return e;
     for (void* p : ws.queues) (void)hipFree(p);
     for (void* p : ws.hit_buffers) (void)hipFree(p);
+    if (ws.bundles) (void)hipFree(ws.bundles);
+    ws.bundles = nullptr;
     ws.queues.clear();
     ws.hit_buffers.clear();
     ws.in_use.clear();
@@ -1020,6 +1263,8 @@ hipError_t prepare_workspace(const DScene& scene, const DParams& params, hipStre
     }
     if (ws.capacity == 0) ws.capacity = want;
     if ((e = ensure_small_buffers(ws)) != hipSuccess) return e;
+    if (may_emit && params.shadows && scene.n_lights > 0 && !ws.bundles &&
+        (e = hipMalloc(&ws.bundles, ws.capacity * sizeof(Bundle))) != hipSuccess) return e;
     if (ws.accum_pixels < npix) {
         if (ws.accum) (void)hipFree(ws.accum);
         ws.accum = nullptr;
@@ -1051,7 +1296,9 @@ hipError_t wavefront_reserve(WavefrontWorkspace& ws, size_t rays_per_queue, int 
         ws.hit_buffers.push_back(h);
         ws.in_use.push_back(0);
     }
+    if (!ws.bundles && (e = hipMalloc(&ws.bundles, ws.capacity * sizeof(Bundle))) != hipSuccess) return e;
     // first touch of every page here, not inside the first frame
+    if ((e = hipMemsetAsync(ws.bundles, 0, ws.capacity * sizeof(Bundle), stream)) != hipSuccess) return e;
     for (size_t i = 0; i < ws.queues.size(); ++i) {
         if ((e = hipMemsetAsync(ws.queues[i], 0, ws.capacity * sizeof(RayRec), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(ws.hit_buffers[i], 0, ws.capacity * sizeof(HitRec), stream)) != hipSuccess) return e;
@@ -1069,6 +1316,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (!ws.fixed && (e = prepare_workspace(scene, params, stream, ws, npix, may_emit, &max_queue_rays)) != hipSuccess) return e;
     if (ws.levels_overflowed && ws.overflowed_scene != scene.serial) ws.levels_overflowed = false;   // another scene: try again
     if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;   // rays traced inside k_shadow
 
     if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
     const size_t first_event = ws.events_used;
@@ -1114,6 +1362,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
                 if (D.err != hipSuccess) break;
                 if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
                 if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+                if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
                 ws.events_used = first_event;
                 D.rays_traced = 0;
                 if ((q = D.acquire()) < 0) break;
@@ -1144,9 +1393,10 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         }
         ws.events_used = first_event;
         hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, ws.host_counts[0], ws.host_counts[1], ws.host_counts[2],
-                           (unsigned long long)(ms * 1e6), ws.host_counts[4], ws.host_counts[5], ws.host_counts[6]);
+                           (unsigned long long)(ms * 1e6), ws.host_counts[4], ws.host_counts[5], ws.host_counts[6], ws.stats + 7);
     } else if (d_counters) {
-        hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, D.rays_traced, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull);
+        hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, D.rays_traced, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull,
+                           ws.stats + 7);
     }
     return hipGetLastError();
 }
@@ -1197,9 +1447,9 @@ hipError_t launch_render_wavefront_static(const DScene& scene, const DParams& pa
     const size_t need = (size_t)tree_levels(scene, params) + 2;
     const size_t room = kStaticScratchBytes - kStaticQueuesOffset;
     size_t capacity = size_t(1) << 20;
-    while (capacity > 4096 && capacity * (sizeof(RayRec) + sizeof(HitRec)) * need > room) capacity >>= 1;
+    while (capacity > 4096 && capacity * ((sizeof(RayRec) + sizeof(HitRec)) * need + sizeof(Bundle)) > room) capacity >>= 1;
     if ((size_t)params.width * 8 > capacity) return hipErrorInvalidValue;
-    const size_t n_queues = room / (capacity * (sizeof(RayRec) + sizeof(HitRec)));
+    const size_t n_queues = (room - capacity * sizeof(Bundle)) / (capacity * (sizeof(RayRec) + sizeof(HitRec)));
     WavefrontWorkspace ws;
     ws.fixed = true;
     ws.capacity = capacity;
@@ -1208,7 +1458,8 @@ hipError_t launch_render_wavefront_static(const DScene& scene, const DParams& pa
     ws.accum = reinterpret_cast<double*>(base + kStaticAccumOffset);
     ws.accum_pixels = (size_t)kStaticMaxPixels;
     ws.host_readback = g_scratch_readback[device];
-    unsigned char* q = base + kStaticQueuesOffset;
+    ws.bundles = base + kStaticQueuesOffset;
+    unsigned char* q = base + kStaticQueuesOffset + capacity * sizeof(Bundle);
     for (size_t i = 0; i < n_queues; ++i) {
         ws.queues.push_back(q);
         ws.hit_buffers.push_back(q + capacity * sizeof(RayRec));
