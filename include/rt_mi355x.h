@@ -318,6 +318,16 @@ int rt_release_workspaces(void);
 int rt_render_linear(rt_scene_t scene, const RtRenderParams* params, double* rgb_out);
 int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb_f64, void* hip_stream);
 
+/* Progressive, resumable accumulation with the running sum in HBM (the reference's sample loop,
+ * main.cpp:288-308, is all or nothing).  rt_accumulate_device renders `passes` passes of params->samples_per_pixel
+ * samples each -- pass k of the series with seed params->seed + first_pass + k (RT_RNG_SEEDED) -- and ADDS each pass's
+ * linear average to d_sum_f64 (3 doubles per pixel of this part, compact tile order, zeroed by the caller before the
+ * first pass), asynchronously on `hip_stream`: nothing crosses PCIe until the caller wants a picture or a checkpoint
+ * (sum + pass count).  rt_resolve_sum_device turns the sum of `passes` passes into the bytes Image::setPixel would hold:
+ * divide, tone map, truncate (main.cpp:308-320, tracer.h:23-54,297-308). */
+int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d_sum_f64, uint64_t first_pass, int passes, void* hip_stream);
+int rt_resolve_sum_device(const void* d_sum_f64, uint64_t passes, int width, int rows, int tonemap, void* d_rgb8, void* hip_stream);
+
 /* Device time (hipEvents on the launch stream) of the BVH-traversal kernel launches that rt_render_device enqueued on
  * `hip_stream` for this scene since the last call of this function, and how many launches that was.  The stream must
  * have been synchronised by the caller (RT_ERR_DEVICE otherwise).  No counterpart in the reference: it feeds the

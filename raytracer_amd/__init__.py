@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
     "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_render_device_noalloc", "rt_reserve",
     "rt_release_workspaces", "rt_comm_unique_id", "rt_comm_init", "rt_comm_rank", "rt_comm_world", "rt_comm_destroy",
-    "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered",
+    "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered", "rt_accumulate_device", "rt_resolve_sum_device",
 ]
 
 
@@ -174,6 +174,8 @@ def _load():
         "rt_comm_world": (i32, []), "rt_comm_destroy": (i32, []),
         "rt_gather_frames": (i32, [vp, i32, i32, i32, i32, vp, vp]),
         "rt_render_gathered": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
+        "rt_accumulate_device": (i32, [vp, C.POINTER(RtRenderParams), vp, C.c_uint64, i32, vp]),
+        "rt_resolve_sum_device": (i32, [vp, C.c_uint64, i32, i32, i32, vp, vp]),
         "rt_deinterleave_device": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rt_part_rows": (i32, [i32, i32, i32, i32]),
         "rt_part_scatter": (i32, [vp, vp, i32, i32, i32, i32, i32]),
@@ -534,6 +536,10 @@ class Scene:
         (torch: `stream.cuda_stream`); None is the null stream, i.e. torch's default stream."""
         _check(lib.rt_render_device(self._h, C.byref(params), d_rgb8_ptr, d_counters_ptr, int(collect_counters), stream))
 
+    def accumulate_device(self, params, d_sum_ptr, first_pass, passes, stream=None):
+        """Add `passes` passes (seeds params.seed + first_pass ...) to the FP64 sum in device memory (rt_accumulate_device)."""
+        _check(lib.rt_accumulate_device(self._h, C.byref(params), d_sum_ptr, int(first_pass), int(passes), stream))
+
     def render_device_noalloc(self, params, d_rgb8_ptr, stream=None):
         """rt_render_device through the library's static workspace: no device allocation (see rt_render_device_noalloc)."""
         _check(lib.rt_render_device_noalloc(self._h, C.byref(params), d_rgb8_ptr, stream))
@@ -551,6 +557,10 @@ class Scene:
 
     def __del__(self):
         self.close()
+
+
+def resolve_sum_device(d_sum_ptr, passes, width, rows, tonemap, d_rgb8_ptr, stream=None):
+    _check(lib.rt_resolve_sum_device(d_sum_ptr, int(passes), int(width), int(rows), int(tonemap), d_rgb8_ptr, stream))
 
 
 def write_pfm(path, img):

@@ -755,6 +755,40 @@ int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void
     return RT_OK;
 }
 
+// Progressive accumulation with the running sum in HBM: pass k of the series is rendered with seed params->seed + k.
+int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d_sum_f64, uint64_t first_pass, int passes, void* hip_stream) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!d_sum_f64) return fail(RT_ERR_INVALID, "d_sum_f64 is NULL");
+    if (passes < 0) return fail(RT_ERR_INVALID, "passes must be >= 0");
+    if (!params) return fail(RT_ERR_INVALID, "NULL argument");
+    if (params->rng_mode != RT_RNG_SEEDED) return fail(RT_ERR_INVALID, "progressive accumulation needs RT_RNG_SEEDED: identical passes add nothing");
+    if (params->schedule != RT_SCHEDULE_WAVEFRONT) return fail(RT_ERR_INVALID, "linear output needs the wavefront schedule");
+    RtRenderParams p = *params;
+    DParams dp;
+    int rc = make_dparams(scene, &p, 0, &dp);
+    if (rc) return rc;
+    if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
+    if (dp.part_rows == 0) return RT_OK;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    WavefrontWorkspace& ws = *workspace_of(st, true);
+    for (int k = 0; k < passes; ++k) {
+        dp.seed = params->seed + first_pass + static_cast<uint64_t>(k);
+        hipError_t e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, ws, static_cast<double*>(d_sum_f64), true);
+        if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    }
+    return RT_OK;
+}
+
+int rt_resolve_sum_device(const void* d_sum_f64, uint64_t passes, int width, int rows, int tonemap, void* d_rgb8, void* hip_stream) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!d_sum_f64 || !d_rgb8 || width <= 0 || rows < 0 || passes == 0) return fail(RT_ERR_INVALID, "rt_resolve_sum_device: bad argument");
+    if (tonemap < 0 || tonemap > 3) return fail(RT_ERR_INVALID, "unknown tonemap mode");
+    hipError_t e = launch_resolve_sum(static_cast<const double*>(d_sum_f64), passes, static_cast<size_t>(width) * rows, tonemap,
+                                      static_cast<uint8_t*>(d_rgb8), static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("resolve kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_render_linear(rt_scene_t scene, const RtRenderParams* params, double* rgb_out) {
     if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
     if (!scene || !params || !rgb_out) return fail(RT_ERR_INVALID, "NULL argument");

@@ -46,9 +46,12 @@ void wavefront_workspace_free(WavefrontWorkspace& ws);
 
 // Wavefront schedule (render_wavefront.hip): same pixels; work is enqueued on `stream`, and the call returns after the
 // last queue has been drained (it reads queue sizes back between levels).
-// d_linear != NULL: instead of RGB8, write the per-pixel average before tone mapping as 3 doubles per pixel.
+// d_linear != NULL: instead of RGB8, write the per-pixel average before tone mapping as 3 doubles per pixel (add_linear:
+// add it to what d_linear holds -- progressive accumulation on the device).
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear = nullptr);
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear = nullptr, bool add_linear = false);
+// Sum of `passes` linear pass averages (interleaved RGB doubles) -> average, tone map, 8 bits (main.cpp:308-320).
+hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, size_t npix, int tonemap, uint8_t* d_rgb8, hipStream_t stream);
 
 // Device time of the k_traverse launches enqueued through `ws` since the last collection (their stream must have been
 // synchronised: hipErrorNotReady otherwise), and how many launches that was.

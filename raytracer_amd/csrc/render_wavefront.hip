@@ -939,9 +939,22 @@ __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, u
 
 // Linear radiance (the average before tone mapping) for float output and progressive accumulation.
 __global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const int n3,
-                                                           const int spp) {
+                                                           const int spp, const int add) {
     const int i = blockIdx.x * kBlock + threadIdx.x;   // interleaved RGB out, planes in
-    if (i < n3) out[i] = accum[(size_t)(i % 3) * (size_t)(n3 / 3) + i / 3] * (1.0 / spp);
+    if (i >= n3) return;
+    const double v = accum[(size_t)(i % 3) * (size_t)(n3 / 3) + i / 3] * (1.0 / spp);
+    out[i] = add ? out[i] + v : v;   // add: a pass of a progressive render joins the running sum in HBM
+}
+
+// Progressive render: the sum of `passes` pass averages -> the picture so far (average, tone map, truncate: main.cpp:308-320).
+__global__ void __launch_bounds__(kBlock) k_resolve_sum(const double* __restrict__ sum, uint8_t* __restrict__ out, const size_t npix,
+                                                        const double inv_passes, const int mode) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const D3 avg = tonemap(mk(sum[i * 3 + 0], sum[i * 3 + 1], sum[i * 3 + 2]) * inv_passes, mode);
+    out[i * 3 + 0] = quantise(avg.x);
+    out[i * 3 + 1] = quantise(avg.y);
+    out[i * 3 + 2] = quantise(avg.z);
 }
 
 // ------------------------------------------------------------------------------------------ host driver
@@ -1306,8 +1319,15 @@ hipError_t wavefront_reserve(WavefrontWorkspace& ws, size_t rays_per_queue, int 
     return hipStreamSynchronize(stream);
 }
 
+hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, size_t npix, int tonemap_mode, uint8_t* d_rgb8, hipStream_t stream) {
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve_sum, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_sum, d_rgb8, npix,
+                       1.0 / (double)(passes ? passes : 1ull), tonemap_mode);
+    return hipGetLastError();
+}
+
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear) {
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, bool add_linear) {
     const size_t npix = (size_t)params.part_rows * params.width;
     if (npix == 0) return hipSuccess;
     hipError_t e;
@@ -1375,7 +1395,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (D.err != hipSuccess) return D.err;
     if (d_linear)
         hipLaunchKernelGGL(k_resolve_linear, dim3((unsigned)((npix * 3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_linear,
-                           (int)(npix * 3), params.spp);
+                           (int)(npix * 3), params.spp, add_linear ? 1 : 0);
     else if (!D.direct)
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
                            params.spp, params.tonemap);

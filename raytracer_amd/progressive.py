@@ -1,4 +1,4 @@
-"""Progressive, resumable accumulation on top of rt_render_linear.
+"""Progressive, resumable accumulation on top of rt_accumulate_device.
 
 The reference renders `samples_per_pixel` samples in one go and stores only tone-mapped bytes (Code/main.cpp:281-322),
 so a 1024-spp 4K frame is all or nothing.  Here a frame is built from passes: every pass renders `spp_per_pass`
@@ -44,46 +44,58 @@ def to_image(linear, tonemap_mode):
 
 
 class ProgressiveRender:
-    """Sum of linear passes of one scene.  `params.samples_per_pixel` is the sample count of ONE pass; pass k is rendered
-    with seed `params.seed + k` (RT_RNG_SEEDED) so that passes are independent and a resumed run continues the series."""
+    """Sum of linear passes of one scene, kept in HBM (C-ABI rt_accumulate_device): `params.samples_per_pixel` is the
+    sample count of ONE pass; pass k is rendered with seed `params.seed + k` (RT_RNG_SEEDED) so that passes are
+    independent and a resumed run continues the series.  Nothing is read back until a picture (`image`: resolved on the
+    device, 3 bytes per pixel) or the sum itself (`sum`, `linear`, `save`: one copy of 24 bytes per pixel) is asked for."""
 
     def __init__(self, scene, params):
+        import torch
         if params.rng_mode != rt.RT_RNG_SEEDED:
             raise ValueError("progressive accumulation needs the seeded RNG: identical passes add nothing")
         self.scene, self.params = scene, params.copy()
         self.base_seed = int(params.seed)
-        self.sum = np.zeros((scene.height, scene.width, 3), dtype=np.float64)
+        self._torch = torch
+        self._dsum = torch.zeros((scene.height, scene.width, 3), dtype=torch.float64, device="cuda")
         self.passes = 0
 
     @property
     def samples(self):
         return self.passes * int(self.params.samples_per_pixel)
 
+    @property
+    def sum(self):
+        return self._dsum.cpu().numpy()
+
     def add_passes(self, n=1):
-        for _ in range(n):
-            p = self.params.copy()
-            p.seed = self.base_seed + self.passes
-            self.sum += self.scene.render_linear(p)
-            self.passes += 1
+        p = self.params.copy()
+        p.seed = self.base_seed
+        self.scene.accumulate_device(p, self._dsum.data_ptr(), self.passes, n, stream=self._torch.cuda.current_stream().cuda_stream)
+        self.passes += n
         return self
 
     def linear(self):
         return self.sum / max(1, self.passes)
 
     def image(self):
-        return to_image(self.linear(), int(self.params.tonemap))
+        """The picture so far: average, tone map and 8-bit truncation on the device (rt_resolve_sum_device)."""
+        out = self._torch.empty((self.scene.height, self.scene.width, 3), dtype=self._torch.uint8, device="cuda")
+        rt.resolve_sum_device(self._dsum.data_ptr(), max(1, self.passes), self.scene.width, self.scene.height, int(self.params.tonemap),
+                              out.data_ptr(), stream=self._torch.cuda.current_stream().cuda_stream)
+        return out.cpu().numpy()
 
     def save(self, path):
         """Checkpoint: the running sum, the pass count and what the passes were rendered with."""
-        np.savez_compressed(path, sum=self.sum, passes=self.passes, base_seed=self.base_seed,
-                            spp_per_pass=int(self.params.samples_per_pixel), shape=np.array(self.sum.shape))
+        s = self.sum
+        np.savez_compressed(path, sum=s, passes=self.passes, base_seed=self.base_seed,
+                            spp_per_pass=int(self.params.samples_per_pixel), shape=np.array(s.shape))
 
     def load(self, path):
         """Resume from a checkpoint written by save() for the same scene and per-pass sample count."""
         with np.load(path, allow_pickle=False) as z:
-            if tuple(z["shape"]) != self.sum.shape or int(z["spp_per_pass"]) != int(self.params.samples_per_pixel):
+            if tuple(z["shape"]) != tuple(self._dsum.shape) or int(z["spp_per_pass"]) != int(self.params.samples_per_pixel):
                 raise ValueError("checkpoint does not belong to this frame (resolution or samples per pass differ)")
-            self.sum = z["sum"].astype(np.float64)
+            self._dsum.copy_(self._torch.from_numpy(z["sum"].astype(np.float64)))
             self.passes = int(z["passes"])
             self.base_seed = int(z["base_seed"])
         return self

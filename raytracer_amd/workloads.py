@@ -60,3 +60,30 @@ def bvh_stress_scene_text(n_spheres, width=1920, height=1080, seed=12345):
     blocks = ["SPHERE\n  translation %.9f %.9f %.9f\n  rotation_euler_radians 0.000000000 0.000000000 %.9f\n  scale %.9f %.9f %.9f\nEND_SPHERE\n"
               % (tx[i], ty[i], tz[i], rz[i], sc[i, 0], sc[i, 1], sc[i, 2]) for i in range(n)]
     return head + "\n".join(blocks)
+
+
+def analytic_sky(width=4096, height=2048):
+    """The HDR environment of BASELINE config 4 ("4k HDR environment"): the reference tree's .pfm / .hdr files are
+    missing blobs, so the sky is written by formula, seed-free -- a vertical gradient, a warm horizon band, a sun disc of
+    radiance 40 and a faint checker so that a wrong texel shows.  float32 [height, width, 3], row 0 = first row of the PFM
+    payload (v = 0, direction -z, HDRImage.cpp:112-182)."""
+    v = (np.arange(height, dtype=np.float64) / (height - 1))[:, None]
+    u = (np.arange(width, dtype=np.float64) / (width - 1))[None, :]
+    sky = np.empty((height, width, 3), dtype=np.float64)
+    horizon = np.exp(-((v - 0.5) / 0.08) ** 2)
+    sky[..., 0] = 0.15 + 0.55 * v + 0.5 * horizon + 0.0 * u
+    sky[..., 1] = 0.25 + 0.50 * v + 0.3 * horizon + 0.0 * u
+    sky[..., 2] = 0.95 - 0.35 * v + 0.1 * np.cos(2.0 * np.pi * u)
+    sun = np.exp(-(((u - 0.62) / 0.012) ** 2 + ((v - 0.71) / 0.024) ** 2))
+    sky += 40.0 * sun[..., None]
+    checker = ((np.arange(height)[:, None] // 64 + np.arange(width)[None, :] // 64) % 2).astype(np.float64)
+    sky *= (0.96 + 0.04 * checker)[..., None]
+    return sky.astype(np.float32)
+
+
+def write_pfm_float32(path, img):
+    """Little-endian "PF" file of a float32 [H, W, 3] array, rows in array order (what HDRImage::load reads)."""
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(np.ascontiguousarray(img, dtype="<f4").tobytes())

@@ -42,6 +42,31 @@ def flags_to_kwargs(flags):
     return kw, shutter
 
 
+_SKY_ROOT = None
+
+
+def sky_texture_root():
+    """A texture root like tests/golden/scenes whose ../Textures also holds sky4k.pfm, the analytic 4096x2048 HDR environment
+    of config 4 (100 MB: written by formula once per test session, never committed; the golden was rendered by the
+    reference with the same file, oracle/gen_golden_r2.py)."""
+    global _SKY_ROOT
+    if _SKY_ROOT is None:
+        import atexit
+        import shutil
+        import tempfile
+        from raytracer_amd import workloads
+        root = tempfile.mkdtemp(prefix="rt_sky_")
+        atexit.register(shutil.rmtree, root, ignore_errors=True)
+        os.makedirs(os.path.join(root, "scenes"))
+        os.makedirs(os.path.join(root, "Textures"))
+        tex = os.path.join(GOLD, "Textures")
+        for f in os.listdir(tex):
+            os.symlink(os.path.join(tex, f), os.path.join(root, "Textures", f))
+        workloads.write_pfm_float32(os.path.join(root, "Textures", "sky4k.pfm"), workloads.analytic_sky())
+        _SKY_ROOT = os.path.join(root, "scenes")
+    return _SKY_ROOT
+
+
 def load_case(name, rng="d0", **extra):
     """-> (SceneFile, RtRenderParams, golden image or None)"""
     with open(os.path.join(GOLD, "configs", name + ".json")) as f:
@@ -50,7 +75,8 @@ def load_case(name, rng="d0", **extra):
     kw.update(extra)
     with open(os.path.join(GOLD, "scenes", name + ".txt"), newline="") as f:
         text = f.read()
-    scene = rt.SceneFile(text=text, texture_root=os.path.join(GOLD, "scenes"), config=cfg, shutter_time=shutter)
+    texture_root = sky_texture_root() if "../Textures/sky4k.pfm" in text else os.path.join(GOLD, "scenes")
+    scene = rt.SceneFile(text=text, texture_root=texture_root, config=cfg, shutter_time=shutter)
     params = cfg.params(rng=rng, **kw)
     img_path = os.path.join(GOLD, "images", name + ".npz")
     golden = np.load(img_path)["image"] if os.path.exists(img_path) else None

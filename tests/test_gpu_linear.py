@@ -52,3 +52,43 @@ def test_progressive_passes_and_resume(gpu, tmp_path):
     assert more.samples == 64
     assert helpers.psnr(more.image(), hi) >= psnr_ref + 2.0
     scene.close()
+
+
+def test_accumulation_stays_on_the_device(gpu):
+    """rt_accumulate_device keeps the FP64 sum in HBM across passes: 16 passes x 4 spp of the motion-blur scene (config 5's)
+    at 3840x2160 with ONE read-back at the end.  The sum equals the passes rendered one by one through rt_render_linear
+    (checked at a size where that is cheap), the picture resolved on the device is the host-side tone map of the sum, and
+    two halves of the series (seeds continue) are the whole."""
+    import re
+    import torch
+    scene_file, params, hi, lo, psnr_ref = helpers.load_stochastic("st_motion_blur", 4, 11)
+    scene = rt.Scene(scene_file)
+    pr = progressive.ProgressiveRender(scene, params).add_passes(3)
+    one_by_one = np.zeros((scene.height, scene.width, 3))
+    for k in range(3):
+        p = params.copy()
+        p.seed = int(params.seed) + k
+        one_by_one += scene.render_linear(p)
+    assert np.allclose(pr.sum, one_by_one, rtol=1e-9, atol=1e-12)
+    mx, nd, _ = helpers.diff_stats(pr.image(), progressive.to_image(pr.linear(), int(params.tonemap)))
+    assert mx <= 1 and nd <= 1e-3 * one_by_one.size
+    halves = progressive.ProgressiveRender(scene, params).add_passes(1).add_passes(2)
+    assert np.allclose(halves.sum, pr.sum, rtol=1e-12, atol=1e-12)
+    scene.close()
+    # config 5's frame size: 4K, 16 passes x 4 spp = 64 spp, nothing read back until the end
+    with open(os.path.join(helpers.GOLD, "scenes", "st_motion_blur.txt"), newline="") as f:
+        text = re.sub(r"(?im)^(\s*resolution\s+)\d+\s+\d+", r"\g<1>3840 2160", f.read())
+    with open(os.path.join(helpers.GOLD, "configs", "st_motion_blur.json")) as f:
+        cfg = rt.Config(text=f.read())
+    kw, shutter = helpers.flags_to_kwargs(helpers.MANIFEST["st_motion_blur"]["flags"])
+    sf = rt.SceneFile(text=text, texture_root=os.path.join(helpers.GOLD, "scenes"), config=cfg, shutter_time=shutter)
+    p4 = cfg.params(rng="seeded", aa=4, seed=3, **{k: v for k, v in kw.items() if k != "aa"})
+    big = rt.Scene(sf)
+    run = progressive.ProgressiveRender(big, p4).add_passes(16)
+    assert run.samples == 64
+    img = run.image()
+    torch.cuda.synchronize()
+    assert img.shape == (2160, 3840, 3)
+    small = img.reshape(54, 40, 96, 40, 3).mean(axis=(1, 3))       # 96x54 box-filtered: the golden's size
+    assert helpers.psnr(small, hi) >= 30.0, helpers.psnr(small, hi)
+    big.close()

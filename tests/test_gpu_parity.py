@@ -78,22 +78,26 @@ def test_row_tile_partition_reassembles(gpu):
     scene.close()
 
 
-def test_full_hd_frame_matches_the_reference_binary(gpu):
+def test_full_hd_frame_matches_the_reference(gpu):
     """A frame of BASELINE's config 2 at a size the REAL reference still loads in seconds (10^5 ellipsoids, 1920x1080,
-    1 spp): oracle/_ref/ref_raytracer (the reference's own sources, compiled in place; it travels with the tree) renders
-    the scene text, the HIP path renders the same text parsed by rt_scene_file_parse, with every hierarchy builder."""
+    1 spp).  The reference's frame is a committed fixture -- every 8th row, rendered by oracle/_ref/ref_raytracer from
+    the same scene text (oracle/gen_golden_r2.py) -- so the comparison never depends on the binary being present; when
+    it is (it travels with the tree), the whole frame is compared too.  Every hierarchy builder."""
     import os
     import run_ref
     from raytracer_amd import workloads
-    if not os.path.exists(run_ref.REF_BIN):
-        pytest.skip("reference binary not built (make -C oracle ref)")
-    text = workloads.bvh_stress_scene_text(100_000, 1920, 1080)
+    fixture = np.load(os.path.join(helpers.GOLD, "images", "c2_100k_rows8.npz"))
+    rows, step, n = fixture["rows"], int(fixture["row_step"]), int(fixture["n_spheres"])
+    text = workloads.bvh_stress_scene_text(n, 1920, 1080)
     cfg_text = open(workloads.DEFAULT_CONFIG_PATH).read()
-    ref_img, _ = run_ref.run_reference(text, cfg_text, flags=["--parallel"], rng="d0", threads=16)
+    ref_img = None
+    if os.path.exists(run_ref.REF_BIN):
+        ref_img, _ = run_ref.run_reference(text, cfg_text, flags=["--parallel"], rng="d0", threads=16)
+        assert np.array_equal(ref_img[::step], rows)   # the fixture is what the reference renders
     cfg = rt.Config(text=cfg_text)
     scene_file = rt.SceneFile(text=text, texture_root=".", config=cfg)
     params = cfg.params(rng="d0")
-    for builder in ("sah", "lbvh"):
+    for builder in ("sah", "lbvh", "sah_gpu"):
         rt.set_bvh_builder(builder)
         try:
             scene = rt.Scene(scene_file)
@@ -101,5 +105,8 @@ def test_full_hd_frame_matches_the_reference_binary(gpu):
             rt.set_bvh_builder("default")
         img = scene.render(params)
         scene.close()
-        mx, nd, _ = helpers.diff_stats(img, ref_img)
-        assert mx <= TOL and nd <= MAX_OFF_FRACTION * img.size, (builder, mx, nd)
+        mx, nd, _ = helpers.diff_stats(img[::step], rows)
+        assert mx <= TOL and nd <= MAX_OFF_FRACTION * rows.size, (builder, mx, nd)
+        if ref_img is not None:
+            mx, nd, _ = helpers.diff_stats(img, ref_img)
+            assert mx <= TOL and nd <= MAX_OFF_FRACTION * img.size, (builder, mx, nd)
