@@ -44,8 +44,15 @@ from raytracer_amd.distributed import FrameGather, init_comm  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NODE_BYTES = 64           # one DNode4: four quantised child boxes + child references (device_types.h)
-SPHERE_BYTES = 16 + 144   # DPrim header + DXform (device_types.h)
+SPHERE_BYTES_LAYOUT = 16 + 144   # what a sphere test really reads here: DPrim header + FP64 DXform (device_types.h)
+SPHERE_BYTES_SURVEY = 64         # SURVEY 8(d)'s constant (3x4 FP32 inverse affine + ids)
 RAY_STATE_BYTES = 16      # amortised framebuffer + ray state traffic per ray
+# VALU peak of the chip in lane-operations: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (MI355X_MICROARCH.md); one
+# wave instruction of 64 lanes takes 4 cycles on a SIMD whatever its lanes do, so (instructions x active lanes) per second
+# against this figure is issue fraction x active-lane fraction: the share of the machine's lane-cycles doing work.
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+FLOPS_PER_BOX_TEST, FLOPS_PER_SPHERE_TEST = 22, 60
+VALU_PEAK_FP32_TFLOPS = 157.3
 
 
 def parse_args():
@@ -62,6 +69,7 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=8,
                     help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the timings of the other BASELINE configs (C1, C3, C4, C5 share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI; the measured configuration) or gloo "
                     "(rehearsal of the multi-rank control flow with the ranks sharing the visible GPUs; slices are staged through the host)")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="CPU baseline renders every k-th row of the same frame")
@@ -131,6 +139,51 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+def other_configs(dev):
+    """The other BASELINE configs on this GPU (N = 1 only, after the headline): whole frames from the committed fixtures at the
+    configs' sizes, scene resident, output in HBM; rays from an untimed counting pass.  The kernel that dominates each frame
+    and its share come from the committed kernel traces (profiles/config_kernels.json), labelled as such."""
+    import tempfile
+    shares = {}
+    sp = os.path.join(ROOT, "profiles", "config_kernels.json")
+    if os.path.exists(sp):
+        try:
+            shares = json.load(open(sp))
+        except Exception:
+            shares = {}
+    res = []
+    stream = torch.cuda.Stream(dev)
+    with tempfile.TemporaryDirectory(prefix="rt_bench_") as scratch:
+        for label, name, w, h, spp, rng in workloads.BASELINE_CONFIGS:
+            try:
+                sf, p = workloads.golden_scene(name, w, h, spp, rng, sky_dir=scratch)
+                sc = rt.Scene(sf)
+                _, st = sc.render(p, stats=True)
+                buf = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize(dev)
+                sc.render_device(p, buf.data_ptr(), stream=stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                reps = 2 if st.rays > 2e8 else 10
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(stream):
+                    e0.record(stream)
+                    for _ in range(reps):
+                        sc.render_device(p, buf.data_ptr(), stream=stream.cuda_stream)
+                    e1.record(stream)
+                torch.cuda.synchronize(dev)
+                ms = e0.elapsed_time(e1) / reps
+                sc.close()
+                k = shares.get(name, {})
+                res.append({"config": label, "fixture": name, "resolution": [w, h], "spp": spp, "rays_per_frame": int(st.rays),
+                            "ms": round(ms, 3), "Mrays_per_s": round(st.rays / ms / 1e3, 1), "frames_timed": reps,
+                            "dominant_kernel": k.get("kernel"), "dominant_kernel_fraction": k.get("fraction"),
+                            "dominant_kernel_source": k.get("source")})
+            except Exception as e:   # the headline does not depend on these
+                res.append({"config": label, "fixture": name, "error": str(e)[:200]})
+        rt.release_workspaces()
+    return res
 
 
 def main():
@@ -317,21 +370,70 @@ def main():
             frame_ok = bool(torch.equal(whole, last.frame))
         dist.barrier()
 
+    # one frame at a time (latency setting) and the boundary's own contract -- rt_render into a HOST buffer (main.cpp:242,320)
+    solo_ms, host_ms = None, None
+    if world == 1:
+        torch.cuda.synchronize(dev)
+        n_solo = max(5, min(args.steps, 20))
+        t1 = time.perf_counter()
+        for _ in range(n_solo):
+            step(slot=0)
+            torch.cuda.synchronize(dev)
+        solo_ms = (time.perf_counter() - t1) * 1e3 / n_solo
+        scene.traverse_time(streams[0].cuda_stream)
+        p_host = params.copy()
+        p_host.part_count, p_host.part_index = 1, 0
+        scene.render(p_host)
+        t1 = time.perf_counter()
+        for _ in range(n_solo):
+            scene.render(p_host)
+        host_ms = (time.perf_counter() - t1) * 1e3 / n_solo
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = rays_frame * args.steps / elapsed / 1e6
-        alg_bytes = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES + rays_rank * RAY_STATE_BYTES
-        achieved = alg_bytes / (traverse_ms * 1e-3) / 1e9 if traverse_ms > 0 else 0.0
-        traffic, valu = None, None   # from the committed rocprofv3 --pmc passes of this workload (profiles/): not measurable in-process
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        boxes_rank = int(c[1])
+        alg_bytes = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES_LAYOUT + rays_rank * RAY_STATE_BYTES
+        alg_bytes_survey = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES_SURVEY + rays_rank * RAY_STATE_BYTES
+        alg_flops = boxes_rank * FLOPS_PER_BOX_TEST + prims_rank * FLOPS_PER_SPHERE_TEST
+        kt = traverse_ms * 1e-3
+        # What bounds k_traverse is VALU issue under divergence, not memory (the hierarchy is served by L2 / Infinity Cache:
+        # measured HBM traffic is ~6 % of the algorithmic bytes).  The instruction and active-lane counts of a launch are fixed
+        # by the build and the frame; they come from the committed rocprofv3 --pmc passes of this workload and are divided by
+        # the launch duration measured live here.
+        pmc = None
+        tp = os.path.join(ROOT, "profiles", "pmc_c2.json")
         if os.path.exists(tp):
             try:
                 t = json.load(open(tp))
-                if t.get("spheres") == args.spheres and t.get("n_gpus", 1) == world:
-                    traffic = t.get("bytes_per_launch")
-                    valu = t.get("valu")
+                if t.get("spheres") == args.spheres and t.get("n_gpus", 1) == world and (args.width, args.height) == (1920, 1080):
+                    pmc = t
             except Exception:
-                traffic, valu = None, None
+                pmc = None
+        roof = {"bound": "valu", "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches_alone,
+                "kernel_ms_in_flight": round(traverse_ms_in_flight, 4), "kernel_launches_in_flight": launches,
+                "unit": "Tlane-op/s", "peak": round(VALU_PEAK_TLANEOPS, 2), "achieved": None, "frac": None, "traffic": None,
+                "algorithmic": {"flops_per_launch": alg_flops, "TFLOP_per_s": round(alg_flops / kt / 1e12, 3) if kt > 0 else None,
+                                "frac_of_fp32_vector_peak": round(alg_flops / kt / 1e12 / VALU_PEAK_FP32_TFLOPS, 5) if kt > 0 else None,
+                                "flops_per_ray": "22*box_tests + 60*sphere_tests (SURVEY 8(d))"},
+                "node_bytes_per_s": {"GB_per_s_survey_constants": round(alg_bytes_survey / kt / 1e9, 1) if kt > 0 else None,
+                                     "GB_per_s_this_layout": round(alg_bytes / kt / 1e9, 1) if kt > 0 else None,
+                                     "bytes_per_launch_survey_constants": alg_bytes_survey, "bytes_per_launch_this_layout": alg_bytes,
+                                     "bytes_per_ray": "64*node_fetches + B*sphere_tests + 16, B = 64 (SURVEY 8(d)) or 160 (DPrim 16 + FP64 DXform 144)",
+                                     "note": "algorithmic bytes, served by L2 / Infinity Cache: not HBM traffic (see traffic)"}}
+        if pmc and kt > 0:
+            v = pmc["valu"]
+            lane_ops = v["wave_instructions_per_launch"] * 64.0 * v["active_lane_fraction"]
+            roof["achieved"] = round(lane_ops / kt / 1e12, 3)
+            roof["frac"] = round(lane_ops / kt / 1e12 / VALU_PEAK_TLANEOPS, 4)
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["valu"] = {"wave_instructions_per_launch": v["wave_instructions_per_launch"], "active_lane_fraction": v["active_lane_fraction"],
+                            "issue_fraction": round(v["wave_instructions_per_launch"] * 4.0 / (1024 * 2.4e9 * kt), 4)}
+            roof["hbm"] = {"GB_per_s_measured": round(pmc["hbm_bytes_per_launch"] / kt / 1e9, 1) if pmc.get("hbm_bytes_per_launch") else None,
+                           "frac_of_peak": round(pmc["hbm_bytes_per_launch"] / kt / 1e9 / HBM_PEAK_GBS, 4) if pmc.get("hbm_bytes_per_launch") else None,
+                           "l2_hit_rate": pmc.get("l2_hit_rate")}
+            roof["pmc_source"] = {"file": "profiles/pmc_c2.json", "build": pmc.get("build"), "collected": pmc.get("collected"),
+                                  "note": "counter totals per launch come from that file (separate rocprofv3 --pmc passes); only the durations are measured in this run"}
         out = {
             "metric": "Mrays/s (primary+secondary) & ms/frame, 1080p Whitted, 1/2/4/8 GPUs", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -344,20 +446,24 @@ def main():
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
                        "frames_in_flight": F, "frames_per_gather": (F if batched else 1) if world > 1 else None, "scene_create_ms": round(t_create * 1e3, 1),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rays_per_lane": os.environ.get("RT_RAYS_PER_LANE"),
                        "gathered_frame_equals_whole_frame": frame_ok},
             "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches_alone,
-                         "kernel_ms_in_flight": round(traverse_ms_in_flight, 4), "kernel_launches_in_flight": launches,
-                         "frame_latency_ms": round(render_ms, 4), "valu": valu,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_ray": "64*node_fetches + 160*sphere_tests + 16"},
+            "frame_latency_ms_in_flight": round(render_ms, 4),
+            "ms_per_frame_solo": round(solo_ms, 4) if solo_ms else None,
+            "Mrays_per_s_solo": round(rays_frame / solo_ms / 1e3, 1) if solo_ms else None,
+            "ms_per_frame_host_buffer": round(host_ms, 4) if host_ms else None,
+            "Mrays_per_s_host_buffer": round(rays_frame / host_ms / 1e3, 1) if host_ms else None,
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             p1 = params.copy()
             p1.part_count, p1.part_index = 1, 0
             out["cpu_baseline"] = cpu_baseline(scene_desc, p1, args.cpu_row_step, args.cpu_passes)
+        if world == 1 and not args.no_configs:
+            scene.close()
+            rt.release_workspaces()
+            out["configs"] = other_configs(dev)
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

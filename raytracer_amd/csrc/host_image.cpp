@@ -130,8 +130,14 @@ static bool convert_with_pil(const char* interpreter, const std::string& src, co
         "    sys.exit(1)\n";
     char* const argv[] = {const_cast<char*>(interpreter), const_cast<char*>("-c"), const_cast<char*>(kScript),
                           const_cast<char*>(src.c_str()), const_cast<char*>(dst.c_str()), nullptr};
+    // what the child prints (PIL's error text for a missing or broken file) goes to stderr: stdout belongs to the caller
+    posix_spawn_file_actions_t fa;
+    if (posix_spawn_file_actions_init(&fa) != 0) return false;
+    posix_spawn_file_actions_adddup2(&fa, 2, 1);
     pid_t pid = 0;
-    if (posix_spawnp(&pid, interpreter, nullptr, nullptr, argv, environ) != 0) return false;
+    const int rc = posix_spawnp(&pid, interpreter, &fa, nullptr, argv, environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return false;
     int status = 0;
     while (waitpid(pid, &status, 0) < 0)
         if (errno != EINTR) return false;

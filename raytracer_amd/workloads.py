@@ -87,3 +87,75 @@ def write_pfm_float32(path, img):
     with open(path, "wb") as f:
         f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
         f.write(np.ascontiguousarray(img, dtype="<f4").tobytes())
+
+
+# ---------------------------------------------------------------------------------------- the other BASELINE configs
+# Scenes of configs 1, 3, 4 and 5 as bench.py and the profiling scripts render them: the committed fixtures under
+# tests/golden/ (scene text + config text + reference-style flags; the reference tree itself is never read at run time)
+# with only the `resolution` line and the sample count changed.
+_REPO = os.path.dirname(_HERE)
+GOLDEN_DIR = os.path.join(_REPO, "tests", "golden")
+BASELINE_CONFIGS = [   # label, fixture, width, height, samples per pixel, sampling
+    ("C1: ASCII/scene.txt, Whitted 1 spp", "c1_default", 1920, 1080, 1, "d0"),
+    ("C1 + --shadows --fresnel", "c1_shadows_fresnel", 1920, 1080, 1, "d0"),
+    ("C3: dof.txt, soft shadows + glossy + depth of field, 64 spp", "st_dof", 1920, 1080, 64, "seeded"),
+    ("C4: displaced + textured + bump-mapped shapes, metal + glass, 4096x2048 HDR environment, ACES", "c4_combined", 1920, 1080, 1, "d0"),
+    ("C5 share: motion_blur.txt, 3840x2160, 16 of the 1024 spp (cost is linear in spp)", "st_motion_blur", 3840, 2160, 16, "seeded"),
+]
+
+
+def _flags_to_kwargs(flags):
+    """Reference CLI flags (main.cpp:82-216) -> (Config.params keyword arguments, shutter time override or None)."""
+    kw, shutter, i = {}, None, 0
+    simple = {"--shadows": "shadows", "--glossy": "glossy", "--fresnel": "fresnel", "--normals": "normals", "--no-bvh": "no_bvh"}
+    while i < len(flags):
+        f = flags[i]
+        if f in simple:
+            kw[simple[f]] = 1
+        elif f == "--aa":
+            kw["aa"] = int(flags[i + 1]); i += 1
+        elif f == "--exposure":
+            kw["exposure"] = float(flags[i + 1]); i += 1
+        elif f == "--tonemap":
+            kw["tonemap"] = flags[i + 1]; i += 1
+        elif f == "--motion-blur":
+            shutter = float(flags[i + 1]); i += 1
+        i += 1
+    return kw, shutter
+
+
+def golden_scene(name, width=None, height=None, spp=None, rng="d0", seed=7, sky_dir=None):
+    """-> (SceneFile, RtRenderParams) of a committed fixture, optionally at another resolution / sample count.  A scene
+    that names ../Textures/sky4k.pfm (config 4) gets the analytic sky written into `sky_dir` (a scratch directory the
+    caller owns) next to links to the committed small textures."""
+    import json
+    import re
+    with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
+        flags = json.load(f)[name]["flags"]
+    with open(os.path.join(GOLDEN_DIR, "configs", name + ".json")) as f:
+        cfg = rt.Config(text=f.read())
+    kw, shutter = _flags_to_kwargs(flags)
+    if spp is not None:
+        kw["aa"] = spp
+    if rng == "seeded":
+        kw["seed"] = seed
+    with open(os.path.join(GOLDEN_DIR, "scenes", name + ".txt"), newline="") as f:
+        text = f.read()
+    if width is not None:
+        text, n = re.subn(r"(?im)^(\s*resolution\s+)\d+\s+\d+", lambda m: "%s%d %d" % (m.group(1), width, height), text)
+        assert n == 1, name
+    root = os.path.join(GOLDEN_DIR, "scenes")
+    if "../Textures/sky4k.pfm" in text:
+        assert sky_dir is not None, "this scene needs a scratch directory for the analytic sky"
+        os.makedirs(os.path.join(sky_dir, "scenes"), exist_ok=True)
+        os.makedirs(os.path.join(sky_dir, "Textures"), exist_ok=True)
+        tex = os.path.join(GOLDEN_DIR, "Textures")
+        for f in os.listdir(tex):
+            if not os.path.lexists(os.path.join(sky_dir, "Textures", f)):
+                os.symlink(os.path.join(tex, f), os.path.join(sky_dir, "Textures", f))
+        sky = os.path.join(sky_dir, "Textures", "sky4k.pfm")
+        if not os.path.exists(sky):
+            write_pfm_float32(sky, analytic_sky())
+        root = os.path.join(sky_dir, "scenes")
+    scene = rt.SceneFile(text=text, texture_root=root, config=cfg, shutter_time=shutter)
+    return scene, cfg.params(rng=rng, **kw)

@@ -11,23 +11,18 @@ CASES = [  # label, golden case, width, height, spp, rng
     ("C1 default scene, Whitted 1 spp", "c1_default", 1920, 1080, 1, "d0"),
     ("C1 + --shadows --fresnel", "c1_shadows_fresnel", 1920, 1080, 1, "d0"),
     ("C3 dof: soft shadows + glossy + DoF, 64 spp", "st_dof", 1920, 1080, 64, "seeded"),
-    ("C4-like: displaced/textured shapes + env + glass, ACES/filmic", "own_complex", 1920, 1080, 1, "d0"),
+    ("C4: config 4 as specified (c4_combined)", "c4_combined", 1920, 1080, 1, "d0"),
+    ("C4-like: displaced shapes only", "own_complex", 1920, 1080, 1, "d0"),
     ("C4-like: glass + HDR environment", "own_glass_env", 1920, 1080, 1, "d0"),
     ("C5-like: motion blur + area lights, 4K 16 spp", "st_motion_blur", 3840, 2160, 16, "seeded"),
 ]
 
+import tempfile
+from raytracer_amd import workloads
+_SCRATCH = tempfile.mkdtemp(prefix="rt_cfg_")
+
 def load(name, w, h, spp, rng):
-    with open(os.path.join(helpers.GOLD, "configs", name + ".json")) as f:
-        cfg = rt.Config(text=f.read())
-    kw, shutter = helpers.flags_to_kwargs(helpers.MANIFEST[name]["flags"])
-    kw["aa"] = spp
-    if rng == "seeded": kw["seed"] = 7
-    with open(os.path.join(helpers.GOLD, "scenes", name + ".txt"), newline="") as f:
-        text = f.read()
-    text, n = re.subn(r"(?im)^(\s*resolution\s+)\d+\s+\d+", lambda m: "%s%d %d" % (m.group(1), w, h), text)
-    assert n == 1, name
-    scene = rt.SceneFile(text=text, texture_root=os.path.join(helpers.GOLD, "scenes"), config=cfg, shutter_time=shutter)
-    return scene, cfg.params(rng=rng, **kw)
+    return workloads.golden_scene(name, w, h, spp, rng, sky_dir=_SCRATCH)
 
 def main():
     rt.init(0)
@@ -36,6 +31,8 @@ def main():
         if only and name not in only: continue
         spp = int(os.environ.get("RT_BENCH_SPP", spp)) if spp > 1 else spp
         sf, params = load(name, w, h, spp, rng)
+        if os.environ.get("RT_BENCH_SCHEDULE") == "mega":
+            params.schedule = rt.RT_SCHEDULE_MEGAKERNEL
         scene = rt.Scene(sf)
         import torch
         dev = torch.device("cuda", 0)
@@ -63,4 +60,8 @@ def main():
         scene.close()
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import shutil
+        shutil.rmtree(_SCRATCH, ignore_errors=True)

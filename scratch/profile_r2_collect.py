@@ -1,0 +1,73 @@
+"""scratch/profile_r2_collect.py <tag>: digest gpurun_out/prof_<tag>/ (scratch/profile_r2.sh) into the committed files under
+profiles/: kernel-stats CSVs, PMC summaries, pmc_c2.json (what bench.py's roofline reads) and config_kernels.json."""
+import collections, csv, glob, json, os, re, shutil, subprocess, sys, time
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = "gpurun_out/prof_%s" % tag
+build = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+for f in ("c2_kernel_stats_1inflight.csv", "c2_kernel_stats_8inflight.csv", "bench_1inflight.json", "bench_8inflight.json"):
+    shutil.copy(os.path.join(src, f), "profiles/%s_%s" % (rnd, f))
+
+def kname(k):
+    m = re.search(r"(k_[a-z_]+)", k)
+    return m.group(1) if m else None
+
+def pmc(prefix):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob("%s/%s_*/**/*counter_collection.csv" % (src, prefix), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+c2 = pmc("pmc")
+with open("profiles/%s_c2_pmc_summary.txt" % rnd, "w") as o:
+    o.write("# rocprofv3 --pmc, one pass per run (scratch/profile_r2.sh), bench.py --frames-in-flight 1, build %s\n" % build)
+    for k in c2:
+        o.write("[%s] mean per launch over %d launches\n" % (k, len(next(iter(c2[k].values())))))
+        for c, v in sorted(c2[k].items()):
+            o.write("  %-36s %.6g\n" % (c, sum(v) / len(v)))
+t = {c: sum(v) / len(v) for c, v in c2["k_traverse"].items()}
+stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "c2_kernel_stats_1inflight.csv"))) if kname(r["Name"])}
+kt = float(stats["k_traverse"]["AverageNs"]) * 1e-9
+read_b = 128 * t.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * t.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * t.get("TCC_EA0_RDREQ_32B_sum", 0)
+write_b = t.get("WRITE_SIZE", 0) * 1024
+out = {"kernel": "k_traverse", "spheres": 1000000, "n_gpus": 1, "build": build, "collected": time.strftime("%Y-%m-%d"),
+       "kernel_ms_in_trace": round(kt * 1e3, 4),
+       "hbm_bytes_per_launch": int(read_b + write_b), "hbm_read_bytes": int(read_b), "hbm_write_bytes": int(write_b),
+       "l2_hit_rate": round(t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"]), 4),
+       "valu": {"wave_instructions_per_launch": int(t["SQ_INSTS_VALU"]),
+                "active_lane_fraction": round(t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_INSTS_VALU"]), 4),
+                "issue_fraction_in_trace": round(t["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * kt), 4)},
+       "method": "rocprofv3 --pmc, separate passes: HBM reads = 128*TCC_EA0_RDREQ_128B + 64*..._64B + 32*..._32B (FETCH_SIZE reads half on gfx950, "
+                 "MI355X_MICROARCH.md), writes = WRITE_SIZE*1024; active lanes = SQ_THREAD_CYCLES_VALU / (64*SQ_INSTS_VALU); "
+                 "issue fraction = SQ_INSTS_VALU*4 cycles / (1024 SIMDs * 2.4 GHz * kernel time)",
+       "source": "profiles/%s_c2_pmc_summary.txt, profiles/%s_c2_kernel_stats_1inflight.csv" % (rnd, rnd)}
+json.dump(out, open("profiles/pmc_c2.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+
+cfg = {}
+for f in sorted(glob.glob(os.path.join(src, "cfg_*_kernel_stats.csv"))):
+    name = re.match(r"cfg_(.*)_kernel_stats.csv", os.path.basename(f)).group(1)
+    shutil.copy(f, "profiles/%s_cfg_%s_kernel_stats.csv" % (rnd, name))
+    rows = [(kname(r["Name"]), int(r["TotalDurationNs"])) for r in csv.DictReader(open(f))]
+    tot = sum(v for k, v in rows)
+    ks = collections.Counter()
+    for k, v in rows:
+        ks[k or "copies and fills"] += v
+    top, tv = ks.most_common(1)[0]
+    cfg[name] = {"kernel": top, "fraction": round(tv / tot, 3), "shares": {k: round(v / tot, 3) for k, v in ks.most_common(5)},
+                 "source": "profiles/%s_cfg_%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats, build %s)" % (rnd, name, build)}
+    j = os.path.join(src, "cfg_%s.json" % name)
+    if os.path.exists(j):
+        shutil.copy(j, "profiles/%s_cfg_%s.json" % (rnd, name))
+json.dump(cfg, open("profiles/config_kernels.json", "w"), indent=1)
+print(json.dumps(cfg, indent=1))
+c3 = pmc("c3pmc")
+with open("profiles/%s_c3_pmc_summary.txt" % rnd, "w") as o:
+    o.write("# rocprofv3 --pmc, one pass per run, scratch/bench_configs.py st_dof at 8 spp (6 frames per run), build %s: totals over the run\n" % build)
+    for k in c3:
+        o.write("[%s] %d launches\n" % (k, len(next(iter(c3[k].values())))))
+        for c, v in sorted(c3[k].items()):
+            o.write("  %-28s %.6g\n" % (c, sum(v)))
