@@ -710,37 +710,42 @@ __global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S
                                                   const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
                                                   const EmitCtx E, double* __restrict__ accum) {
     __shared__ SceneStage<SMALL> staged;
-    const unsigned n = n_device ? min(*n_device, n_host) : n_host;   // see k_traverse; the grid covers n_host
+    const unsigned n = n_device ? min(*n_device, n_host) : n_host;   // see k_traverse
     if (blockIdx.x * kBlock >= n) return;
     const DScene S = staged.stage(S0);
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    D3 c = mk(0.0, 0.0, 0.0);
-    int pixel = -1 - lane;   // lanes without a contribution: a run of their own
-    if (i < n) {
-        const RayRec q = ray_load(rays, i);
-        const HitRec hr = hit_load(hits, i);
-        D3 contrib = mk(0.0, 0.0, 0.0);
-        if (shade_ray<F, EMIT>(S, P, q, hr, E, contrib)) {
-            c = contrib;
-            pixel = q.pixel;
+    // The host sizes the grid by the count when it knows it, and by the machine when the count is on the device (a level
+    // enqueued without a round trip: its bound is often orders of magnitude above what is really there, and a hundred
+    // thousand workgroups that only find out that they have nothing to do cost more than a small level's work).
+    for (unsigned base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const unsigned i = base + threadIdx.x;
+        D3 c = mk(0.0, 0.0, 0.0);
+        int pixel = -1 - lane;   // lanes without a contribution: a run of their own
+        if (i < n) {
+            const RayRec q = ray_load(rays, i);
+            const HitRec hr = hit_load(hits, i);
+            D3 contrib = mk(0.0, 0.0, 0.0);
+            if (shade_ray<F, EMIT>(S, P, q, hr, E, contrib)) {
+                c = contrib;
+                pixel = q.pixel;
+            }
         }
-    }
-    if (E.direct) {
-        if (pixel >= 0) deposit(E, P, accum, pixel, c);
-        return;
-    }
-    // runs of equal pixel: [first lane whose left neighbour differs, lane before the next such lane]
-    const int left = __shfl_up(pixel, 1);
-    const unsigned long long heads = __ballot(lane == 0 || left != pixel);
-    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const int run_end = above ? lane + __ffsll((long long)above) - 1 : 63;
+        if (E.direct) {
+            if (pixel >= 0) deposit(E, P, accum, pixel, c);
+            continue;
+        }
+        // runs of equal pixel: [first lane whose left neighbour differs, lane before the next such lane]
+        const int left = __shfl_up(pixel, 1);
+        const unsigned long long heads = __ballot(lane == 0 || left != pixel);
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int run_end = above ? lane + __ffsll((long long)above) - 1 : 63;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double ox = __shfl_down(c.x, d), oy = __shfl_down(c.y, d), oz = __shfl_down(c.z, d);
-        if (lane + d <= run_end) { c.x += ox; c.y += oy; c.z += oz; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const double ox = __shfl_down(c.x, d), oy = __shfl_down(c.y, d), oz = __shfl_down(c.z, d);
+            if (lane + d <= run_end) { c.x += ox; c.y += oy; c.z += oz; }
+        }
+        if (pixel >= 0 && ((heads >> lane) & 1ull)) accum_add(accum, P, pixel, c);
     }
-    if (pixel >= 0 && ((heads >> lane) & 1ull)) accum_add(accum, P, pixel, c);
 }
 
 // ------------------------------------------------------------------------------------------ k_shadow
@@ -874,9 +879,15 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles, const unsigned
 template <int F>
 __global__ void __launch_bounds__(kBlock, 4)
 k_traverse_small(const DScene S0, const DParams P, const RayQ rays, const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
-                 unsigned long long* __restrict__ counters) {
+                 unsigned long long* __restrict__ counters, unsigned* __restrict__ zero_a, unsigned* __restrict__ zero_b) {
     __shared__ SmallSceneLds small_lds;
     const unsigned n = n_device ? min(*n_device, n_host) : n_host;
+    // the words this level's shading kernel counts into (next queue's size, shadow bundles) start at zero: one store here
+    // instead of a fill launch each (the kernels of a stream run one after the other)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (zero_a) *zero_a = 0u;
+        if (zero_b) *zero_b = 0u;
+    }
     if (blockIdx.x * kBlock >= n) return;   // (whole workgroup: before the barrier of the staging)
     const DScene S = stage_small_scene(S0, small_lds);
     if (n_device && blockIdx.x == 0 && threadIdx.x == 0 && n != 0u) atomicAdd(&counters[0], (unsigned long long)n);
@@ -1029,7 +1040,8 @@ struct Driver {
     template <int F> void launch_traverse_kernel(int q, unsigned n, const unsigned* n_device) {
         if (small_scene()) {
             const unsigned blocks = std::max(1u, std::min((n + kBlock - 1) / kBlock, (unsigned)ws.compute_units * 16u));
-            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, ws.stats);
+            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, ws.stats, zero_a, zero_b);
+            zero_a = zero_b = nullptr;
             return;
         }
         // Persistent grid sized by the work: at least RT_RAYS_PER_LANE rays per lane, so that lanes can be refilled and
@@ -1044,6 +1056,7 @@ struct Driver {
             hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
                                ws.counters + kNextBase, ws.stats);
     }
+    unsigned *zero_a = nullptr, *zero_b = nullptr;   // words the next small-scene traversal launch zeroes (run_levels)
     bool with_shadows() const { return may_emit && P.shadows && S.n_lights > 0; }
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && getenv("RT_NO_SMALL_SCENE") == nullptr; }
     EmitCtx emit_ctx(int qo, unsigned* count) {
@@ -1073,7 +1086,9 @@ struct Driver {
     template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr,
                                        unsigned* count = nullptr) {
         const EmitCtx E = emit_ctx(qo, count);
-        const dim3 grid((n + kBlock - 1) / kBlock);
+        // (n is a bound when the count lies on the device: see k_shade)
+        const unsigned full = (n + kBlock - 1) / kBlock;
+        const dim3 grid(n_device ? std::min(full, (unsigned)ws.compute_units * 16u) : full);
         if (may_emit && small_scene())
             hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
         else if (may_emit)
@@ -1110,13 +1125,15 @@ struct Driver {
         for (; level < levels && err == hipSuccess; ++level) {
             const unsigned* n_dev = level == 0 ? nullptr : cnt + (level & 1);
             const unsigned n = (unsigned)bound;
-            if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) break;
+            unsigned* out_count = cnt + ((level + 1) & 1);
+            const bool small = small_scene();
+            if (small) { zero_a = out_count; zero_b = ws.counters + kBundleCount; }   // k_traverse_small zeroes them itself
+            else if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) break;
             traverse(q, n, n_dev);
             const int qo = acquire();
             if (qo < 0) break;
-            unsigned* out_count = cnt + ((level + 1) & 1);
-            if (!ok(hipMemsetAsync(out_count, 0, sizeof(unsigned), stream))) { release(qo); break; }
-            if (with_shadows() && !ok(hipMemsetAsync(ws.counters + kBundleCount, 0, sizeof(unsigned), stream))) { release(qo); break; }
+            if (!small && !ok(hipMemsetAsync(out_count, 0, sizeof(unsigned), stream))) { release(qo); break; }
+            if (!small && with_shadows() && !ok(hipMemsetAsync(ws.counters + kBundleCount, 0, sizeof(unsigned), stream))) { release(qo); break; }
             shade(q, 0, n, qo, n_dev, out_count);
             shadow(n, qo, out_count);
             release(q);   // stream order: whatever reuses these buffers runs after this level's kernels
