@@ -26,7 +26,8 @@ struct WavefrontWorkspace {
     void* bundles = nullptr;             // shadow bundles of one shading launch: capacity x 128 bytes (allocated with the first frame that has shadows)
     double* accum = nullptr;             // FP64 RGB accumulator per pixel of the part
     size_t accum_pixels = 0;
-    unsigned* counters = nullptr;        // [0] next ray to fetch, [1] rays emitted, [2] overflow flag
+    unsigned* counters = nullptr;        // [2] overflow flag, [4] entries of the queue last summed, [6..7] ray total, [32..] fetch counters
+    unsigned* shard_counts = nullptr;    // tails of the queues' shards: one array per ray-tree level + one for the shadow bundles
     unsigned long long* stats = nullptr; // RT_N_COUNTERS entries: [1] box tests, [2] primitive tests, [4] nodes fetched
     unsigned long long host_counts[RT_N_COUNTERS] = {};
     std::vector<hipEvent_t> events;      // start/stop pairs around the k_traverse launches not yet collected

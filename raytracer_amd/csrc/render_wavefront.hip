@@ -149,6 +149,48 @@ struct Chunk {
     int s0, ns;         // samples [s0, s0 + ns) of every pixel
 };
 
+// Sharded queues.  The tail of a queue is a word that every emitting wave adds to with a returning atomic, and one word
+// takes ~88 such atomics per microsecond (MI355X_MICROARCH.md, dequeue row): a frame of small waves of work -- one hit,
+// one bundle, a child or two per lane -- spends most of its shading time queueing for that word (measured: 532 -> 170 us
+// for the 2 M hits of the C1 frame with the atomics spread over 32 words).  So a queue is cut into `shards` regions of
+// `region` entries, each with a tail of its own (on a 128-byte line of its own), and a wave emits into the shard its
+// input came from (or, reading a dense queue, into shard wave % shards): the children of a wave stay together, the load
+// per shard is bounded (one shard's input times the fan-out), and 32 tails take 32 times the atomics.
+constexpr unsigned kShards = 32;          // shards of a queue when the scene is small (frames of many small levels)
+constexpr unsigned kCountStride = 32;     // words between the tails of neighbouring shards
+constexpr unsigned kCountArrays = 96;     // one array of tails per ray-tree level (reused modulo this)
+constexpr size_t kShardCountBytes = (size_t)(kCountArrays + 1) * kShards * kCountStride * sizeof(unsigned);   // + 1: the bundles' tails
+struct QIn {                              // what a consumer kernel works through
+    const unsigned* counts;               // tails of the shards (word r * kCountStride), or null: `n` entries from index 0 (host count)
+    unsigned n;
+    unsigned shards, region;              // entries of shard r: [r * region + lo, r * region + min(hi, tail))
+    unsigned lo, hi;
+};
+struct BlockSpan {
+    unsigned shard, origin;               // this workgroup's shard and the queue index of its entry 0
+    unsigned begin, end, step;            // the workgroup's first entry (lane 0), the end of the shard's entries, entries between rounds
+};
+// Workgroup b of a grid that is a multiple of `shards` serves shard b % shards, striding over it with the others.
+// `per`: lanes per entry (k_shadow: one lane per shadow ray of a bundle); begin / end / step are then in lanes.
+__device__ __forceinline__ BlockSpan block_span(const QIn& q, unsigned per = 1u) {
+    BlockSpan b;
+    const unsigned k = q.counts ? q.shards : 1u;
+    b.shard = blockIdx.x % k;
+    const unsigned j = blockIdx.x / k, nb = gridDim.x / k;
+    const unsigned tail = q.counts ? min(q.counts[b.shard * kCountStride], q.region) : q.n;
+    b.origin = q.counts ? b.shard * q.region : 0u;
+    b.end = min(tail, q.hi) * per;
+    b.begin = q.lo * per + j * kBlock;
+    b.step = nb * kBlock;
+    return b;
+}
+__device__ __forceinline__ unsigned queue_total(const QIn& q) {   // entries in all shards (one lane's loop)
+    if (!q.counts) return q.n;
+    unsigned t = 0;
+    for (unsigned r = 0; r < q.shards; ++r) t += min(q.counts[r * kCountStride], q.region);
+    return t;
+}
+
 // The accumulators are three planes (all reds, all greens, all blues of the part): float atomics execute at the memory
 // side as 64-byte requests (MI355X_MICROARCH.md, global float atomics), so what an atomic instruction costs is the number
 // of 64-byte segments its lanes touch; neighbouring lanes hold neighbouring pixels, and a plane puts their 8-byte sums
@@ -285,7 +327,7 @@ constexpr unsigned kXcds = 8;
 constexpr unsigned kNextStride = kFetchCounterWords / kXcds;   // counters 128 bytes apart
 constexpr unsigned kNextBase = 32;     // offset of the fetch counters in WavefrontWorkspace::counters
 constexpr unsigned kLevelCountBase = 4;   // two queue-size words of the levels enqueued without a host round trip
-constexpr unsigned kBundleCount = 3;      // shadow bundles written by the current shading launch
+constexpr unsigned kLevelTotal = 6;       // u64: rays of the levels whose size only the device knew (words 2 .. 7 are read back as one piece)
 __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
     return q >= kXcds ? n : (unsigned)(((unsigned long long)n * q / kXcds) & ~63ull);
 }
@@ -296,13 +338,13 @@ template <int F, bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_TRAVERSE_WAVES)
 k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, const unsigned n_host,
            const unsigned* __restrict__ n_device, const unsigned rays_per_block, unsigned* __restrict__ next,
-           unsigned long long* __restrict__ counters) {
+           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total) {
     __shared__ unsigned long long stack_mem[kTravLdsEntries + 1][kBlock];   // + 1: the row branch-free pushes discard into
     // n_device != NULL: the queue was filled by the shading kernel launched before this one and the host has not read
     // its size (levels enqueued without a round trip); n_host is then the queue's capacity, which a count that
     // overflowed is cut to.  One lane adds the level's rays to the frame's total.
     const unsigned n = n_device ? min(*n_device, n_host) : n_host;
-    if (n_device && blockIdx.x == 0 && threadIdx.x == 0 && n != 0u) atomicAdd(&counters[0], (unsigned long long)n);
+    if (n_device && blockIdx.x == 0 && threadIdx.x == 0 && n != 0u) atomicAdd(level_total, (unsigned long long)n);
     // The host sized the grid by the bound it knows; workgroups beyond what the actual count calls for (the host's own
     // rule: rays_per_block rays each) leave at once -- thousands of idle waves polling the eight fetch counters would
     // serialise on them for longer than a small level takes to trace.
@@ -468,7 +510,18 @@ struct EmitCtx {
     BundleQ bundles;   // shadow bundles of this launch's hits (k_shadow traces them), their count, the buffer's capacity
     unsigned* bundle_count;
     unsigned bundle_cap;
+    unsigned shards;   // `count` and `bundle_count` are arrays of this many tails; `cap` / `bundle_cap` are one shard's entries
 };
+// The emission context of one wave: out queue, bundle buffer and their tails narrowed to shard `r`.
+__device__ __forceinline__ EmitCtx emit_view(const EmitCtx& E, unsigned r) {
+    EmitCtx V = E;
+    r %= E.shards;
+    V.out.p = E.out.p ? E.out.p + (size_t)r * E.cap : nullptr;
+    V.count = E.count + r * kCountStride;
+    V.bundles.p = E.bundles.p ? E.bundles.p + (size_t)r * E.bundle_cap : nullptr;
+    V.bundle_count = E.bundle_count + r * kCountStride;
+    return V;
+}
 
 // Contribution c of one ray to its pixel.
 __device__ __forceinline__ void deposit(const EmitCtx& E, const DParams& P, double* accum, int pixel, D3 c) {
@@ -706,26 +759,29 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 #define RT_SHADE_WAVES 1          // waves per SIMD asked of the register allocator for the shading kernel
 #endif
 template <int F, bool EMIT, bool SMALL>
-__global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays,
-                                                  const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
-                                                  const EmitCtx E, double* __restrict__ accum) {
+__global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
+                                                  const HitQ hits_all, const QIn in, const EmitCtx E, double* __restrict__ accum) {
     __shared__ SceneStage<SMALL> staged;
-    const unsigned n = n_device ? min(*n_device, n_host) : n_host;   // see k_traverse
-    if (blockIdx.x * kBlock >= n) return;
+    const BlockSpan span = block_span(in);
+    if (span.begin >= span.end) return;
     const DScene S = staged.stage(S0);
     const int lane = threadIdx.x & 63;
+    const RayQ rays{rays_all.p + span.origin, rays_all.stride};
+    const HitQ hits{hits_all.p + span.origin, hits_all.stride};
     // The host sizes the grid by the count when it knows it, and by the machine when the count is on the device (a level
     // enqueued without a round trip: its bound is often orders of magnitude above what is really there, and a hundred
     // thousand workgroups that only find out that they have nothing to do cost more than a small level's work).
-    for (unsigned base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    for (unsigned base = span.begin; base < span.end; base += span.step) {
         const unsigned i = base + threadIdx.x;
+        // children and bundles of this wave go to the shard its rays came from (a dense queue deals its waves round)
+        const EmitCtx Ew = EMIT ? emit_view(E, in.counts ? span.shard : (base + threadIdx.x) / 64u) : E;
         D3 c = mk(0.0, 0.0, 0.0);
         int pixel = -1 - lane;   // lanes without a contribution: a run of their own
-        if (i < n) {
+        if (i < span.end) {
             const RayRec q = ray_load(rays, i);
             const HitRec hr = hit_load(hits, i);
             D3 contrib = mk(0.0, 0.0, 0.0);
-            if (shade_ray<F, EMIT>(S, P, q, hr, E, contrib)) {
+            if (shade_ray<F, EMIT>(S, P, q, hr, Ew, contrib)) {
                 c = contrib;
                 pixel = q.pixel;
             }
@@ -762,13 +818,18 @@ constexpr int kInlineSegments = 6;
 #endif                            // variants; the variant with the ray marcher and the texture paths spills at that budget (x 1.6)
 template <int F, bool SMALL>
 __global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? 2 : RT_SHADOW_WAVES)
-k_shadow(const DScene S0, const DParams P, const BundleQ bundles, const unsigned* __restrict__ n_bundles, const unsigned cap,
-         const EmitCtx E, double* __restrict__ accum, unsigned long long* __restrict__ stats) {
+k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn in, const EmitCtx E0, double* __restrict__ accum,
+         unsigned long long* __restrict__ stats) {
     __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
     __shared__ SceneStage<SMALL> staged;
     const DScene S = staged.stage(S0);
     const unsigned per = 2u * (unsigned)P.shadow_samples;
-    const unsigned long long n = (unsigned long long)min(*n_bundles, cap) * per;
+    // this workgroup's shard of the bundles (block_span in 64-bit lanes: a bundle is `per` lanes)
+    const unsigned shard = blockIdx.x % in.shards;
+    const unsigned long long n = (unsigned long long)min(in.counts[shard * kCountStride], in.region) * per;
+    const unsigned long long first = (unsigned long long)(blockIdx.x / in.shards) * kBlock, stride = (unsigned long long)(gridDim.x / in.shards) * kBlock;
+    const BundleQ bundles{bundles_all.p + (size_t)shard * in.region, bundles_all.stride};
+    const EmitCtx E = emit_view(E0, shard);   // a chain that goes on as a queued ray stays in the shard
     const int lane = threadIdx.x & 63;
     TravStack stack;
     stack.lds = &stack_mem[0][threadIdx.x];
@@ -777,7 +838,7 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles, const unsigned
     const bool any_hit = S.transparent_materials == 0;
     // the grid is sized by the machine, not by the bound on the bundles (most levels of a ray tree hold far fewer than
     // the bound): every workgroup strides over the rays that are really there
-    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < n; base += (unsigned long long)gridDim.x * kBlock) {
+    for (unsigned long long base = first; base < n; base += stride) {
         const unsigned long long i = base + threadIdx.x;
         D3 c = mk(0.0, 0.0, 0.0);
         int pixel = -1 - lane;
@@ -878,22 +939,30 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles, const unsigned
 // stack -- buys nothing when there is no hierarchy to speak of, and costs most of the time of such frames.
 template <int F>
 __global__ void __launch_bounds__(kBlock, 4)
-k_traverse_small(const DScene S0, const DParams P, const RayQ rays, const HitQ hits, const unsigned n_host, const unsigned* __restrict__ n_device,
-                 unsigned long long* __restrict__ counters, unsigned* __restrict__ zero_a, unsigned* __restrict__ zero_b) {
+k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const HitQ hits_all, const QIn in,
+                 unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total, unsigned* __restrict__ zero_a,
+                 unsigned* __restrict__ zero_b, const unsigned zero_shards) {
     __shared__ SmallSceneLds small_lds;
-    const unsigned n = n_device ? min(*n_device, n_host) : n_host;
-    // the words this level's shading kernel counts into (next queue's size, shadow bundles) start at zero: one store here
+    // the tails this level's shading kernel counts into (next queue's shards, shadow bundles) start at zero: stores here
     // instead of a fill launch each (the kernels of a stream run one after the other)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (zero_a) *zero_a = 0u;
-        if (zero_b) *zero_b = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < zero_shards) {
+        if (zero_a) zero_a[threadIdx.x * kCountStride] = 0u;
+        if (zero_b) zero_b[threadIdx.x * kCountStride] = 0u;
     }
-    if (blockIdx.x * kBlock >= n) return;   // (whole workgroup: before the barrier of the staging)
+    // a level whose size only the device knows joins the frame's ray total
+    if (in.counts && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned t = queue_total(in);
+        if (t != 0u) atomicAdd(level_total, (unsigned long long)t);
+    }
+    const BlockSpan span = block_span(in);
+    if (span.begin >= span.end) return;   // (whole workgroup: before the barrier of the staging)
     const DScene S = stage_small_scene(S0, small_lds);
-    if (n_device && blockIdx.x == 0 && threadIdx.x == 0 && n != 0u) atomicAdd(&counters[0], (unsigned long long)n);
+    const RayQ rays{rays_all.p + span.origin, rays_all.stride};
+    const HitQ hits{hits_all.p + span.origin, hits_all.stride};
+    const unsigned n = span.end;
     const int lane = threadIdx.x & 63;
     Counters C{0u, 0u, 0u, 0u};
-    for (unsigned base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    for (unsigned base = span.begin; base < n; base += span.step) {
         const unsigned i = base + threadIdx.x;
         const bool mine = i < n;
         Ray r{mk(0, 0, 0), mk(0, 0, 1), 0.0};
@@ -948,6 +1017,15 @@ __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, u
     }
 }
 
+// Entries in all shards of a queue -> one word the host reads back (with the overflow flag and the ray total next to it).
+__global__ void k_sum_counts(const unsigned* __restrict__ counts, const unsigned shards, const unsigned region, unsigned* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (unsigned r = 0; r < shards; ++r) t += min(counts[r * kCountStride], region);
+        *out = t;
+    }
+}
+
 // Linear radiance (the average before tone mapping) for float output and progressive accumulation.
 __global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const int n3,
                                                            const int spp, const int add) {
@@ -995,8 +1073,8 @@ struct Driver {
         if (e != hipSuccess && err == hipSuccess) err = e;
         return err == hipSuccess;
     }
-    RayQ rays(int q, unsigned start = 0) { return RayQ{static_cast<rt_q4*>(ws.queues[q]) + start, (unsigned)ws.capacity}; }
-    HitQ hits(int q, unsigned start = 0) { return HitQ{static_cast<rt_q4*>(ws.hit_buffers[q]) + start, (unsigned)ws.capacity}; }
+    RayQ rays(int q) { return RayQ{static_cast<rt_q4*>(ws.queues[q]), (unsigned)ws.capacity}; }
+    HitQ hits(int q) { return HitQ{static_cast<rt_q4*>(ws.hit_buffers[q]), (unsigned)ws.capacity}; }
 
     int acquire() {
         for (size_t i = 0; i < ws.queues.size(); ++i)
@@ -1029,21 +1107,43 @@ struct Driver {
         }
         return ws.events[ws.events_used++];
     }
-    template <int F> void launch_traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
+    // ---- sharded queues (see QIn): level 0 is the dense queue k_raygen wrote; the queue of level l >= 1 has K shards whose
+    //      tails are the array tails(l)
+    unsigned K = 1;
+    unsigned region() const { return (unsigned)(ws.capacity / K); }
+    unsigned* tails(int level) { return ws.shard_counts + (size_t)(level % (int)kCountArrays) * kShards * kCountStride; }
+    unsigned* bundle_tails() { return ws.shard_counts + (size_t)kCountArrays * kShards * kCountStride; }
+    size_t tails_bytes() const { return K == 1 ? sizeof(unsigned) : (size_t)kShards * kCountStride * sizeof(unsigned); }
+    QIn dense(unsigned n, unsigned lo = 0, unsigned hi = 0xffffffffu) { return QIn{nullptr, n, 1u, (unsigned)ws.capacity, lo, std::min(hi, n)}; }
+    QIn sharded(int level, unsigned lo = 0, unsigned hi = 0xffffffffu) { return QIn{tails(level), 0u, K, region(), lo, hi}; }
+    // grid of a kernel that strides over `in`: by the count where the host knows it, else by the machine; a multiple of the shards
+    unsigned grid_for(const QIn& in, unsigned long long bound_lanes) {
+        unsigned long long blocks = (bound_lanes + kBlock - 1) / kBlock;
+        if (!in.counts) return (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(blocks, 0x7fffffffull));
+        blocks = std::min<unsigned long long>(blocks, (unsigned long long)ws.compute_units * 16ull);
+        const unsigned k = in.shards;
+        return (unsigned)std::max<unsigned long long>(k, (blocks + k - 1) / k * k);
+    }
+
+    template <int F> void launch_traverse(int q, const QIn& in, unsigned bound) {
         const bool timed = !ws.fixed && ws.events_used + 2 <= kMaxTimedEvents;
         hipEvent_t e0 = timed ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
         if (e1) (void)hipEventRecord(e0, stream);
-        launch_traverse_kernel<F>(q, n, n_device);
+        launch_traverse_kernel<F>(q, in, bound);
         if (e1) (void)hipEventRecord(e1, stream);
         else if (e0) --ws.events_used;   // keep start/stop pairs whole
     }
-    template <int F> void launch_traverse_kernel(int q, unsigned n, const unsigned* n_device) {
+    template <int F> void launch_traverse_kernel(int q, const QIn& in, unsigned bound) {
+        unsigned long long* level_total = reinterpret_cast<unsigned long long*>(ws.counters + kLevelTotal);
         if (small_scene()) {
-            const unsigned blocks = std::max(1u, std::min((n + kBlock - 1) / kBlock, (unsigned)ws.compute_units * 16u));
-            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, ws.stats, zero_a, zero_b);
+            const unsigned blocks = in.counts ? grid_for(in, bound) : std::max(1u, std::min((bound + kBlock - 1) / kBlock, (unsigned)ws.compute_units * 16u));
+            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), in, ws.stats, level_total, zero_a, zero_b, K);
             zero_a = zero_b = nullptr;
             return;
         }
+        // (scenes with a hierarchy have unsharded queues: K == 1, and the tail of a level is word 0 of its array)
+        const unsigned n = bound;
+        const unsigned* n_device = in.counts;
         // Persistent grid sized by the work: at least RT_RAYS_PER_LANE rays per lane, so that lanes can be refilled and
         // a small queue (a part of a frame, a deep level of the ray tree) leaves the other CUs to concurrent streams.
         const unsigned per_block = kBlock * (unsigned)std::max(1, ws.rays_per_lane);
@@ -1051,107 +1151,109 @@ struct Driver {
         const unsigned blocks = std::max(1u, std::min((unsigned)traverse_blocks, want));
         if (P.count_tests)
             hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
-                               ws.counters + kNextBase, ws.stats);
+                               ws.counters + kNextBase, ws.stats, level_total);
         else
             hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
-                               ws.counters + kNextBase, ws.stats);
+                               ws.counters + kNextBase, ws.stats, level_total);
     }
-    unsigned *zero_a = nullptr, *zero_b = nullptr;   // words the next small-scene traversal launch zeroes (run_levels)
+    unsigned *zero_a = nullptr, *zero_b = nullptr;   // tails the next small-scene traversal launch zeroes (run_levels)
     bool with_shadows() const { return may_emit && P.shadows && S.n_lights > 0; }
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && getenv("RT_NO_SMALL_SCENE") == nullptr; }
-    EmitCtx emit_ctx(int qo, unsigned* count) {
-        return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, count ? count : ws.counters + 1, ws.counters + 2, qo >= 0 ? (unsigned)ws.capacity : 0u, direct,
-                       BundleQ{static_cast<rt_q4*>(ws.bundles), (unsigned)ws.capacity}, ws.counters + kBundleCount,
-                       ws.bundles ? (unsigned)ws.capacity : 0u};
+    // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
+    EmitCtx emit_ctx(int qo, int out_level) {
+        return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, tails(out_level), ws.counters + 2, qo >= 0 ? region() : 0u, direct,
+                       BundleQ{static_cast<rt_q4*>(ws.bundles), (unsigned)ws.capacity}, bundle_tails(), ws.bundles ? region() : 0u, K};
     }
-    // The shadow rays of the hits a shading launch of n rays has just bundled (at most n x lights bundles, never more than the buffer holds).
-    template <int F> void launch_shadow(unsigned n, int qo, unsigned* count) {
-        const EmitCtx E = emit_ctx(qo, count);
+    // The shadow rays of the hits a shading launch of at most n rays has just bundled (at most n x lights bundles).
+    template <int F> void launch_shadow(unsigned n, int qo, int out_level) {
+        const EmitCtx E = emit_ctx(qo, out_level);
+        const QIn in{bundle_tails(), 0u, K, region(), 0u, 0xffffffffu};
         const unsigned long long bound = std::min<unsigned long long>((unsigned long long)n * (unsigned)S.n_lights, ws.capacity) * 2ull * (unsigned)P.shadow_samples;
-        const unsigned long long blocks = std::min<unsigned long long>((bound + kBlock - 1) / kBlock, (unsigned long long)ws.compute_units * 16ull);
-        if (blocks == 0) return;
+        const unsigned blocks = grid_for(in, bound);
         if (small_scene())
-            hipLaunchKernelGGL((k_shadow<F, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, S, P, E.bundles, ws.counters + kBundleCount, E.bundle_cap, E,
-                               ws.accum, ws.stats);
+            hipLaunchKernelGGL((k_shadow<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, ws.accum, ws.stats);
         else
-            hipLaunchKernelGGL((k_shadow<F, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, S, P, E.bundles, ws.counters + kBundleCount, E.bundle_cap, E,
-                               ws.accum, ws.stats);
+            hipLaunchKernelGGL((k_shadow<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, ws.accum, ws.stats);
     }
-    void shadow(unsigned n, int qo, unsigned* count = nullptr) {
+    void shadow(unsigned n, int qo, int out_level) {
         if (!with_shadows()) return;
-        if (variant == 0) launch_shadow<kSpheres>(n, qo, count);
-        else if (variant == 1) launch_shadow<kAnalytic>(n, qo, count);
-        else launch_shadow<kFull>(n, qo, count);
+        if (variant == 0) launch_shadow<kSpheres>(n, qo, out_level);
+        else if (variant == 1) launch_shadow<kAnalytic>(n, qo, out_level);
+        else launch_shadow<kFull>(n, qo, out_level);
     }
-    template <int F> void launch_shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr,
-                                       unsigned* count = nullptr) {
-        const EmitCtx E = emit_ctx(qo, count);
-        // (n is a bound when the count lies on the device: see k_shade)
-        const unsigned full = (n + kBlock - 1) / kBlock;
-        const dim3 grid(n_device ? std::min(full, (unsigned)ws.compute_units * 16u) : full);
+    template <int F> void launch_shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
+        const EmitCtx E = emit_ctx(qo, out_level);
+        const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi)));
+        const QIn& v = in;
         if (may_emit && small_scene())
-            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
         else if (may_emit)
-            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
         else if (small_scene())
-            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
         else
-            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, start), hits(q, start), n, n_device, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
     }
-    void traverse(int q, unsigned n, const unsigned* n_device = nullptr) {
-        if (variant == 0) launch_traverse<kSpheres>(q, n, n_device);
-        else if (variant == 1) launch_traverse<kAnalytic>(q, n, n_device);
-        else launch_traverse<kFull>(q, n, n_device);
+    void traverse(int q, const QIn& in, unsigned bound) {
+        if (variant == 0) launch_traverse<kSpheres>(q, in, bound);
+        else if (variant == 1) launch_traverse<kAnalytic>(q, in, bound);
+        else launch_traverse<kFull>(q, in, bound);
     }
-    void shade(int q, unsigned start, unsigned n, int qo, const unsigned* n_device = nullptr, unsigned* count = nullptr) {
-        if (variant == 0) launch_shade<kSpheres>(q, start, n, qo, n_device, count);
-        else if (variant == 1) launch_shade<kAnalytic>(q, start, n, qo, n_device, count);
-        else launch_shade<kFull>(q, start, n, qo, n_device, count);
+    void shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
+        if (variant == 0) launch_shade<kSpheres>(q, in, bound, qo, out_level);
+        else if (variant == 1) launch_shade<kAnalytic>(q, in, bound, qo, out_level);
+        else launch_shade<kFull>(q, in, bound, qo, out_level);
+    }
+    // entries in all shards of the queue of `level` -> the word next to the overflow flag (read back together)
+    void sum_tails(int level) {
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, tails(level), K, region(), ws.counters + kLevelCountBase);
     }
 
     // A whole ray tree without a host round trip per level: every level's queue size stays on the device (the kernels
-    // of level L + 1 read the count the shading kernel of level L left), grids are sized by what the host knows -- the
+    // of level L + 1 read the tails the shading kernel of level L left), grids are sized by what the host knows -- the
     // level cannot hold more than the previous level's bound times its fan-out, nor more than a queue -- and the queue
     // overflow flag, the size of the last queue and the ray total are read back ONCE at the end.  Optimistic: a level
-    // that outgrows its queue (the kernels never write past it) makes the caller render the frame again level by level
-    // with batches (process()).  Returns 0 = done, 1 = overflow; rays still queued after `levels` levels (chains of
-    // shadow segments through transmitting surfaces) are finished by process().
+    // that outgrows its queue (the kernels never write past a shard) makes the caller render the frame again level by
+    // level with batches (process()).  Returns 0 = done, 1 = overflow; rays still queued after `levels` levels (chains
+    // of shadow segments through transmitting surfaces) are finished by process().
     int run_levels(int q, unsigned n0, int levels) {
-        unsigned* cnt = ws.counters + kLevelCountBase;   // two words, used alternately
-        if (!ok(hipMemsetAsync(ws.counters + 2, 0, sizeof(unsigned), stream))) { release(q); return 0; }
-        if (!ok(hipMemsetAsync(ws.stats, 0, sizeof(unsigned long long), stream))) { release(q); return 0; }
+        // overflow flag, the word the last queue's size goes to, and the ray total start at zero (words 2 .. 7)
+        if (!ok(hipMemsetAsync(ws.counters + 2, 0, 6 * sizeof(unsigned), stream))) { release(q); return 0; }
         size_t bound = n0;
         int level = 0;
         for (; level < levels && err == hipSuccess; ++level) {
-            const unsigned* n_dev = level == 0 ? nullptr : cnt + (level & 1);
+            const QIn in = level == 0 ? dense(n0) : sharded(level);
             const unsigned n = (unsigned)bound;
-            unsigned* out_count = cnt + ((level + 1) & 1);
             const bool small = small_scene();
-            if (small) { zero_a = out_count; zero_b = ws.counters + kBundleCount; }   // k_traverse_small zeroes them itself
+            if (small) { zero_a = tails(level + 1); zero_b = bundle_tails(); }   // k_traverse_small zeroes them itself
             else if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) break;
-            traverse(q, n, n_dev);
+            traverse(q, in, n);
             const int qo = acquire();
             if (qo < 0) break;
-            if (!small && !ok(hipMemsetAsync(out_count, 0, sizeof(unsigned), stream))) { release(qo); break; }
-            if (!small && with_shadows() && !ok(hipMemsetAsync(ws.counters + kBundleCount, 0, sizeof(unsigned), stream))) { release(qo); break; }
-            shade(q, 0, n, qo, n_dev, out_count);
-            shadow(n, qo, out_count);
+            if (!small && !ok(hipMemsetAsync(tails(level + 1), 0, tails_bytes(), stream))) { release(qo); break; }
+            if (!small && with_shadows() && !ok(hipMemsetAsync(bundle_tails(), 0, tails_bytes(), stream))) { release(qo); break; }
+            shade(q, in, n, qo, level + 1);
+            shadow(n, qo, level + 1);
             release(q);   // stream order: whatever reuses these buffers runs after this level's kernels
             q = qo;
             bound = std::min<size_t>(ws.capacity, bound * fanout(level));
         }
-        unsigned local[4] = {0, 0, 0, 0};
-        unsigned* res = ws.host_readback ? ws.host_readback : local;   // [0] last queue's size, [1] overflow flag, [2..3] ray total
+        // (looking every third level whether anything is still queued was measured: a round trip costs ~70 us with the
+        // launches behind it, more than the empty levels of a C1 frame save)
+        unsigned local[6] = {0, 0, 0, 0, 0, 0};
+        unsigned* res = ws.host_readback ? ws.host_readback : local;   // words 2 .. 7 of the counters, read back as one piece
+        unsigned queued = 0, overflowed = 0;
         unsigned long long total = 0;
         if (err == hipSuccess) {
-            ok(hipMemcpyAsync(&res[0], cnt + (level & 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            ok(hipMemcpyAsync(&res[1], ws.counters + 2, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            ok(hipMemcpyAsync(&res[2], ws.stats, sizeof(total), hipMemcpyDeviceToHost, stream));
-            ok(hipStreamSynchronize(stream));
-            memcpy(&total, &res[2], sizeof(total));
+            sum_tails(level);
+            if (ok(hipMemcpyAsync(res, ws.counters + 2, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) && ok(hipStreamSynchronize(stream))) {
+                overflowed = res[0];
+                queued = res[kLevelCountBase - 2];
+                memcpy(&total, &res[kLevelTotal - 2], sizeof(total));
+            }
         }
         if (err != hipSuccess) { release(q); return 0; }
-        if (res[1]) {
+        if (overflowed) {
             // A level outgrew its queue.  At most twice per workspace the queues are doubled for the frames to come
             // (deep ray trees of glass scenes peak well above their first level) -- up to RT_QUEUE_RAYS when that is set,
             // else up to 2^28 rays, and only while the device has room for eight such queues; if that was not enough
@@ -1170,41 +1272,63 @@ struct Driver {
             return 1;
         }
         rays_traced += n0 + total;   // level 0 was launched with a host count
-        if (res[0] != 0u) process(q, res[0], level);
+        if (queued != 0u) process(q, queued, level);
         else release(q);
         return 0;
     }
 
-    // Trace and shade the n rays of queue q (owned by this call, released when fully consumed), then their children.
+    // Trace and shade the n rays of queue q (the queue of `level`; owned by this call, released when fully consumed), then
+    // their children.  The host knows n; with sharded queues (K > 1, level > 0) the kernels still find the entries through
+    // the tails on the device.
     void process(int q, unsigned n, int level) {
         if (err != hipSuccess || n == 0) { release(q); return; }
+        const bool is_dense = level == 0 || K == 1;
         // level 0: k_raygen has zeroed the fetch counters
-        if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) { release(q); return; }
-        traverse(q, n);
+        if (level > 0 && !small_scene() && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) { release(q); return; }
+        traverse(q, is_dense ? dense(n) : sharded(level), n);
         rays_traced += n;
         if (!may_emit) {   // no material spawns rays and shadows are off: shade and return, nothing to read back (asynchronous)
-            shade(q, 0, n, -1);
+            shade(q, dense(n), n, -1, level + 1);
             release(q);
             return;
         }
+        // Batches sized so that the children of a batch always fit: of a dense queue by entries, of a sharded one by the
+        // same range of every shard (a wave's children stay in its shard: a shard's batch times the fan-out fits a shard).
         const size_t fo = fanout(level);
-        const unsigned batch = (unsigned)std::max<size_t>(1, std::min<size_t>(n, ws.capacity / fo));
-        for (unsigned start = 0; start < n && err == hipSuccess; start += batch) {
-            const unsigned m = std::min(batch, n - start);
+        unsigned span = n, batch = (unsigned)std::max<size_t>(1, std::min<size_t>(n, ws.capacity / fo));
+        if (!is_dense) {
+            span = batch = region();
+            if ((size_t)n * fo > ws.capacity) {   // more than one batch: how far the fullest shard reaches
+                std::vector<unsigned> t((size_t)kShards * kCountStride);
+                if (!ok(hipMemcpyAsync(t.data(), tails(level), t.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
+                    release(q);
+                    return;
+                }
+                span = 0;
+                for (unsigned r = 0; r < K; ++r) span = std::max(span, std::min(t[(size_t)r * kCountStride], region()));
+                batch = (unsigned)std::max<size_t>(1, (ws.capacity / fo) / K);
+            }
+        }
+        for (unsigned start = 0; start < span && err == hipSuccess; start += batch) {
+            const unsigned m = std::min(batch, span - start);
+            const unsigned m_total = is_dense ? m : (unsigned)std::min<size_t>(n, (size_t)m * K);
             const int qo = acquire();
             if (qo < 0) break;
-            if (!ok(hipMemsetAsync(ws.counters + 1, 0, 3 * sizeof(unsigned), stream))) { release(qo); break; }   // emitted, overflow, bundles
-            shade(q, start, m, qo);
-            shadow(m, qo);
-            unsigned local[2] = {0, 0};
-            unsigned* res = ws.host_readback ? ws.host_readback : local;
-            if (!ok(hipMemcpyAsync(res, ws.counters + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
+            // overflow flag, the tails of the children's queue and of the bundles
+            if (!ok(hipMemsetAsync(ws.counters + 2, 0, sizeof(unsigned), stream)) || !ok(hipMemsetAsync(tails(level + 1), 0, tails_bytes(), stream)) ||
+                !ok(hipMemsetAsync(bundle_tails(), 0, tails_bytes(), stream))) { release(qo); break; }
+            shade(q, is_dense ? dense(n, start, start + m) : sharded(level, start, start + m), m_total, qo, level + 1);
+            shadow(m_total, qo, level + 1);
+            sum_tails(level + 1);
+            unsigned local[3] = {0, 0, 0};
+            unsigned* res = ws.host_readback ? ws.host_readback : local;   // words 2 .. 4: overflow flag, -, entries queued
+            if (!ok(hipMemcpyAsync(res, ws.counters + 2, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) || !ok(hipStreamSynchronize(stream))) {
                 release(qo);
                 break;
             }
-            if (res[1]) { ok(hipErrorOutOfMemory); release(qo); break; }  // queue overflow: cannot happen with the batching above
-            if (start + m >= n) { release(q); q = -1; }                    // input fully consumed: its buffers may be reused below
-            const unsigned n_children = res[0];
+            if (res[0]) { ok(hipErrorOutOfMemory); release(qo); break; }  // queue overflow: cannot happen with the batching above
+            if (start + m >= span) { release(q); q = -1; }                 // input fully consumed: its buffers may be reused below
+            const unsigned n_children = res[2];
             process(qo, n_children, level + 1);
         }
         if (q >= 0) release(q);
@@ -1220,6 +1344,7 @@ void wavefront_workspace_free(WavefrontWorkspace& ws) {
         if (ws.bundles) (void)hipFree(ws.bundles);
         if (ws.accum) (void)hipFree(ws.accum);
         if (ws.counters) (void)hipFree(ws.counters);
+        if (ws.shard_counts) (void)hipFree(ws.shard_counts);
         if (ws.stats) (void)hipFree(ws.stats);
     }
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
@@ -1260,6 +1385,8 @@ hipError_t ensure_small_buffers(WavefrontWorkspace& ws) {
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&ws.counters), (kNextBase + kXcds * kNextStride) * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&ws.stats), RT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ws.shard_counts), kShardCountBytes)) != hipSuccess) return e;
+    if ((e = hipMemset(ws.shard_counts, 0, kShardCountBytes)) != hipSuccess) return e;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1370,7 +1497,11 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     // Primary rays are generated in chunks of whole 8-row bands x a batch of samples, sized so that the first
     // level's children always fit one queue.
     const size_t fo0 = may_emit ? D.fanout(0) : 1;   // nothing is queued behind the primary rays of such a frame
-    const size_t max_primary = std::max<size_t>(64, ws.capacity / fo0);
+    // Frames of a small scene are many small levels whose cost is the queue tails: their queues are sharded (QIn).  The
+    // waves of the dense first level are dealt to the shards in turn: a shard gets one wave more than its share at most.
+    D.K = (may_emit && D.small_scene() && ws.capacity >= (size_t(1) << 16) && getenv("RT_NO_SHARDS") == nullptr) ? kShards : 1u;
+    const size_t slack = D.K > 1 ? (size_t)128 * D.K : 0;
+    const size_t max_primary = std::max<size_t>(64, ws.capacity / fo0 > slack + 64 ? ws.capacity / fo0 - slack : 64);
     const int W = params.width;
     int ns = (int)std::min<size_t>((size_t)params.spp, std::max<size_t>(1, max_primary / ((size_t)W * 8)));
     int rows_per_chunk = (int)std::min<size_t>((size_t)params.part_rows, std::max<size_t>(8, (max_primary / ((size_t)W * ns)) / 8 * 8));
@@ -1454,7 +1585,8 @@ unsigned char* g_scratch_ptr[kMaxDevices] = {};
 unsigned* g_scratch_readback[kMaxDevices] = {};   // pinned host words for the queue-size read-backs of this variant
 constexpr size_t kStaticCountersOffset = 0;                       // (kNextBase + 256) unsigned words
 constexpr size_t kStaticStatsOffset = 4096;                       // RT_N_COUNTERS u64
-constexpr size_t kStaticAccumOffset = 8192;                       // kStaticMaxPixels x 3 doubles
+constexpr size_t kStaticShardsOffset = 8192;                      // tails of the queue shards (kShardCountBytes)
+constexpr size_t kStaticAccumOffset = kStaticShardsOffset + (kShardCountBytes + 4095) / 4096 * 4096;   // kStaticMaxPixels x 3 doubles
 constexpr size_t kStaticQueuesOffset = kStaticAccumOffset + (size_t)kStaticMaxPixels * 3 * sizeof(double);
 static_assert((kNextBase + kXcds * kNextStride) * sizeof(unsigned) <= kStaticStatsOffset, "counters overlap the statistics words");
 static_assert(kStaticQueuesOffset % 256 == 0 && kStaticQueuesOffset < kStaticScratchBytes, "static scratch layout");
@@ -1492,6 +1624,7 @@ hipError_t launch_render_wavefront_static(const DScene& scene, const DParams& pa
     ws.capacity = capacity;
     ws.counters = reinterpret_cast<unsigned*>(base + kStaticCountersOffset);
     ws.stats = reinterpret_cast<unsigned long long*>(base + kStaticStatsOffset);
+    ws.shard_counts = reinterpret_cast<unsigned*>(base + kStaticShardsOffset);
     ws.accum = reinterpret_cast<double*>(base + kStaticAccumOffset);
     ws.accum_pixels = (size_t)kStaticMaxPixels;
     ws.host_readback = g_scratch_readback[device];
