@@ -1157,6 +1157,8 @@ struct Driver {
                                ws.counters + kNextBase, ws.stats, level_total);
     }
     unsigned *zero_a = nullptr, *zero_b = nullptr;   // tails the next small-scene traversal launch zeroes (run_levels)
+    bool allow_grow = true;   // a frame of one chunk whose ray tree outgrows the queues gets larger queues next time (a frame of
+                              // several chunks sizes its chunks by the queues: larger queues, larger chunks, the same overflow)
     bool with_shadows() const { return may_emit && P.shadows && S.n_lights > 0; }
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && getenv("RT_NO_SMALL_SCENE") == nullptr; }
     // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
@@ -1262,7 +1264,7 @@ struct Driver {
             size_t free_bytes = 0, total_bytes = 0;
             if (!ws.fixed) (void)hipMemGetInfo(&free_bytes, &total_bytes);
             const size_t bigger = std::min(ws.capacity * 2, max_capacity);
-            if (!ws.fixed && ws.grow <= 2 && bigger > ws.capacity && free_bytes >= 8 * bigger * (sizeof(RayRec) + sizeof(HitRec))) {
+            if (!ws.fixed && allow_grow && ws.grow <= 2 && bigger > ws.capacity && free_bytes >= 8 * bigger * (sizeof(RayRec) + sizeof(HitRec))) {
                 ws.grow *= 2;
                 ws.grown_capacity = bigger;
             } else {
@@ -1506,39 +1508,40 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     int ns = (int)std::min<size_t>((size_t)params.spp, std::max<size_t>(1, max_primary / ((size_t)W * 8)));
     int rows_per_chunk = (int)std::min<size_t>((size_t)params.part_rows, std::max<size_t>(8, (max_primary / ((size_t)W * ns)) / 8 * 8));
     if ((size_t)rows_per_chunk * W * ns > ws.capacity) return hipErrorInvalidValue;  // frame wider than the queue: raise RT_QUEUE_RAYS
-    // A frame that is one chunk is first tried without host round trips between the levels of its ray tree
-    // (Driver::run_levels); RT_SYNC_LEVELS=1 keeps the level-by-level path (A/B runs, tests).
-    const bool one_chunk = rows_per_chunk >= params.part_rows && ns >= params.spp;
-    // (a scene whose ray tree outgrew the queues once on this stream is not tried again)
-    const bool optimistic = may_emit && one_chunk && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
+    // A frame is first tried without host round trips between the levels of its ray tree: every chunk of primary rays
+    // enqueues all its levels and is read back once (Driver::run_levels).  A level that outgrows a queue shard makes the
+    // FRAME start over level by level with batches (what the aborted attempt added to the accumulators, the test
+    // counters and the traversal timing is dropped), and the stream's later frames of that scene go that way at once.
+    // RT_SYNC_LEVELS=1 keeps the level-by-level path (A/B runs, tests).
     const int levels = tree_levels(scene, params);
-    for (int row0 = 0; row0 < params.part_rows && D.err == hipSuccess; row0 += rows_per_chunk) {
-        const int rows = std::min(rows_per_chunk, params.part_rows - row0);
-        for (int s0 = 0; s0 < params.spp && D.err == hipSuccess; s0 += ns) {
-            Chunk ck{row0, rows, s0, std::min(ns, params.spp - s0)};
-            const long long n = (long long)rows * W * ck.ns;
-            int q = D.acquire();
-            if (q < 0) break;
-            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
-                               ws.counters + kNextBase);
-            if (optimistic) {
-                const int lr = D.run_levels(q, (unsigned)n, levels);
-                if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] capacity %zu grow %zu -> %s\n", ws.capacity, ws.grow, lr == 0 ? "done" : "overflow");
-                if (lr == 0) continue;
-                // a level outgrew its queue: start the frame over, level by level with batches; what the aborted attempt
-                // added to the accumulators, the test counters and the traversal timing is dropped
-                if (D.err != hipSuccess) break;
-                if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
-                if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-                if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
-                ws.events_used = first_event;
-                D.rays_traced = 0;
-                if ((q = D.acquire()) < 0) break;
+    D.allow_grow = rows_per_chunk >= params.part_rows && ns >= params.spp;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool optimistic = attempt == 0 && may_emit && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
+        bool overflowed = false;
+        for (int row0 = 0; row0 < params.part_rows && D.err == hipSuccess && !overflowed; row0 += rows_per_chunk) {
+            const int rows = std::min(rows_per_chunk, params.part_rows - row0);
+            for (int s0 = 0; s0 < params.spp && D.err == hipSuccess && !overflowed; s0 += ns) {
+                Chunk ck{row0, rows, s0, std::min(ns, params.spp - s0)};
+                const long long n = (long long)rows * W * ck.ns;
+                int q = D.acquire();
+                if (q < 0) break;
                 hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
                                    ws.counters + kNextBase);
+                if (optimistic) {
+                    const int lr = D.run_levels(q, (unsigned)n, levels);
+                    if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] capacity %zu grow %zu -> %s\n", ws.capacity, ws.grow, lr == 0 ? "done" : "overflow");
+                    overflowed = lr != 0;
+                } else {
+                    D.process(q, (unsigned)n, 0);
+                }
             }
-            D.process(q, (unsigned)n, 0);
         }
+        if (!overflowed || D.err != hipSuccess) break;
+        if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
+        if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        ws.events_used = first_event;
+        D.rays_traced = 0;
     }
     if (D.err != hipSuccess) return D.err;
     if (d_linear)
