@@ -33,4 +33,10 @@ cpass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD
 cpass tcc TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum || exit 1
 cpass grbm GRBM_GUI_ACTIVE GRBM_TA_BUSY || exit 1
 rm -rf $out/trace1 $out/trace8
+# keep what the collection step reads (counter_collection.csv of the PMC passes, the copied kernel stats): the traces are large
+for c in c1_default c1_shadows_fresnel st_dof c4_combined st_motion_blur; do rm -rf $out/cfg_$c; done
+# digest on the box (the per-dispatch counter files are tens of MiB; gpurun brings back at most 64 MiB), then drop the raw files
+RT_PROFILE_OUT=$out/digest python3 scratch/profile_r2_collect.py $tag > $out/collect.log 2>&1 || exit 1
+rm -rf $out/pmc_*/ $out/c3pmc_*/
+du -sh $out
 echo "profile set $tag done"

@@ -4,9 +4,12 @@ import collections, csv, glob, json, os, re, shutil, subprocess, sys, time
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = "gpurun_out/prof_%s" % tag
-build = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+# on the GPU box (no .git there) the build id comes in by the environment and the digest goes under gpurun_out/
+build = os.environ.get("RT_BUILD_ID") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dst = os.environ.get("RT_PROFILE_OUT", "profiles")
+os.makedirs(dst, exist_ok=True)
 for f in ("c2_kernel_stats_1inflight.csv", "c2_kernel_stats_8inflight.csv", "bench_1inflight.json", "bench_8inflight.json"):
-    shutil.copy(os.path.join(src, f), "profiles/%s_%s" % (rnd, f))
+    shutil.copy(os.path.join(src, f), "%s/%s_%s" % (dst, rnd, f))
 
 def kname(k):
     m = re.search(r"(k_[a-z_]+)", k)
@@ -22,7 +25,7 @@ def pmc(prefix):
     return acc
 
 c2 = pmc("pmc")
-with open("profiles/%s_c2_pmc_summary.txt" % rnd, "w") as o:
+with open("%s/%s_c2_pmc_summary.txt" % (dst, rnd), "w") as o:
     o.write("# rocprofv3 --pmc, one pass per run (scratch/profile_r2.sh), bench.py --frames-in-flight 1, build %s\n" % build)
     for k in c2:
         o.write("[%s] mean per launch over %d launches\n" % (k, len(next(iter(c2[k].values())))))
@@ -44,13 +47,13 @@ out = {"kernel": "k_traverse", "spheres": 1000000, "n_gpus": 1, "build": build, 
                  "MI355X_MICROARCH.md), writes = WRITE_SIZE*1024; active lanes = SQ_THREAD_CYCLES_VALU / (64*SQ_INSTS_VALU); "
                  "issue fraction = SQ_INSTS_VALU*4 cycles / (1024 SIMDs * 2.4 GHz * kernel time)",
        "source": "profiles/%s_c2_pmc_summary.txt, profiles/%s_c2_kernel_stats_1inflight.csv" % (rnd, rnd)}
-json.dump(out, open("profiles/pmc_c2.json", "w"), indent=1)
+json.dump(out, open(dst + "/pmc_c2.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 cfg = {}
 for f in sorted(glob.glob(os.path.join(src, "cfg_*_kernel_stats.csv"))):
     name = re.match(r"cfg_(.*)_kernel_stats.csv", os.path.basename(f)).group(1)
-    shutil.copy(f, "profiles/%s_cfg_%s_kernel_stats.csv" % (rnd, name))
+    shutil.copy(f, "%s/%s_cfg_%s_kernel_stats.csv" % (dst, rnd, name))
     rows = [(kname(r["Name"]), int(r["TotalDurationNs"])) for r in csv.DictReader(open(f))]
     tot = sum(v for k, v in rows)
     ks = collections.Counter()
@@ -61,11 +64,11 @@ for f in sorted(glob.glob(os.path.join(src, "cfg_*_kernel_stats.csv"))):
                  "source": "profiles/%s_cfg_%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats, build %s)" % (rnd, name, build)}
     j = os.path.join(src, "cfg_%s.json" % name)
     if os.path.exists(j):
-        shutil.copy(j, "profiles/%s_cfg_%s.json" % (rnd, name))
-json.dump(cfg, open("profiles/config_kernels.json", "w"), indent=1)
+        shutil.copy(j, "%s/%s_cfg_%s.json" % (dst, rnd, name))
+json.dump(cfg, open(dst + "/config_kernels.json", "w"), indent=1)
 print(json.dumps(cfg, indent=1))
 c3 = pmc("c3pmc")
-with open("profiles/%s_c3_pmc_summary.txt" % rnd, "w") as o:
+with open("%s/%s_c3_pmc_summary.txt" % (dst, rnd), "w") as o:
     o.write("# rocprofv3 --pmc, one pass per run, scratch/bench_configs.py st_dof at 8 spp (6 frames per run), build %s: totals over the run\n" % build)
     for k in c3:
         o.write("[%s] %d launches\n" % (k, len(next(iter(c3[k].values())))))
