@@ -5,14 +5,19 @@ Metric (BASELINE.json): Mrays/s (primary + secondary) and ms/frame, 1080p Whitte
 Workload: BASELINE config 2 — 10^6 seeded random ellipsoids (raytracer_amd.workloads.bvh_stress_scene), 1920x1080,
 1 spp, default flags, shipped config values; deterministic sampling (RT_RNG_D0) so that every step traces the same rays.
 
-A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernel (C-ABI
-rt_render_device on torch's current stream), the u8 slices are gathered to rank 0 over RCCL and de-interleaved there.
-The scene is already resident in HBM when the timed region starts.  value = rays of all ranks / max-over-ranks time.
-Scaling is "strong": the frame (total work) is fixed as N grows.
+A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernels (C-ABI
+rt_render_device on a HIP stream per frame in flight), the u8 slices travel to rank 0 inside the library
+(rt_gather_frames: RCCL send/recv + k_deinterleave).  The scene is resident in HBM when the timed region starts and the
+frame stays in HBM.  value = rays of all ranks / max-over-ranks time.  Scaling is "strong": the frame is fixed as N grows.
+`python bench.py --gpus N` without a launcher's environment starts its N ranks itself (torch.distributed.run) and fails
+when fewer GPUs are visible; it never prints an N=1 line for N>1.
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (BVH-node + primitive bytes per second of the render kernel,
-HIP events around each launch, against the 8 TB/s HBM peak) and "cpu_baseline" (the CPU oracle, OpenMP, on this
-host's cores; N=1 only).
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" of k_traverse -- bound "valu": useful lane-operations per second
+(VALU wave-instructions x 64 x active-lane fraction from the committed PMC passes, profiles/pmc_c2.json, over the kernel
+time measured live with HIP events) against 39.32 Tlane-op/s; "traffic" = measured HBM bytes per launch; the SURVEY 8(d)
+node bytes per second under both per-sphere constants -- then "cpu_baseline" (the CPU oracle, OpenMP, on this host's
+cores, checked against the real reference binary where that exists; N=1 only) and "configs" (the other BASELINE
+configurations timed whole-frame, with the kernel that dominates each from profiles/config_kernels.json).
 """
 import argparse
 import ctypes as C
