@@ -5,9 +5,10 @@ Metric (BASELINE.json): Mrays/s (primary + secondary) and ms/frame, 1080p Whitte
 Workload: BASELINE config 2 — 10^6 seeded random ellipsoids (raytracer_amd.workloads.bvh_stress_scene), 1920x1080,
 1 spp, default flags, shipped config values; deterministic sampling (RT_RNG_D0) so that every step traces the same rays.
 
-A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernels (C-ABI
-rt_render_device on a HIP stream per frame in flight), the u8 slices travel to rank 0 inside the library
-(rt_gather_frames: RCCL send/recv + k_deinterleave).  The scene is resident in HBM when the timed region starts and the
+A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernels, 16 frames per call
+(C-ABI rt_render_frames_device: the rays of the frames share the ray queues and one launch of every kernel; two such
+calls in flight on HIP streams of their own), and the u8 slices of the 16 frames travel to rank 0 inside the library in
+one exchange (rt_gather_frames: RCCL send/recv + k_deinterleave).  The scene is resident in HBM when the timed region starts and the
 frame stays in HBM.  value = rays of all ranks / max-over-ranks time.  Scaling is "strong": the frame is fixed as N grows.
 `python bench.py --gpus N` without a launcher's environment starts its N ranks itself (torch.distributed.run) and fails
 when fewer GPUs are visible; it never prints an N=1 line for N>1.
@@ -63,16 +64,17 @@ VALU_PEAK_FP32_TFLOPS = 157.3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--spheres", type=int, default=1_000_000, help="C2 primitive count (default = the named config)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile-rows", type=int, default=8)
-    ap.add_argument("--gather-per-frame", action="store_true",
-                    help="several GPUs: one gather per frame instead of one per --frames-in-flight frames")
-    ap.add_argument("--frames-in-flight", type=int, default=8,
-                    help="frames rendered concurrently, each on its own HIP stream with its own queues and frame buffers")
+    ap.add_argument("--frames-per-launch", type=int, default=16,
+                    help="frames rendered per call (rt_render_frames_device) and sent to rank 0 per exchange")
+    ap.add_argument("--launches-in-flight", type=int, default=2, help="sets of --frames-per-launch frames in flight, each on its own HIP stream")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="the round-1 setting instead: ONE frame per call (rt_render_device), this many in flight on streams of their own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the timings of the other BASELINE configs (C1, C3, C4, C5 share)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI; the measured configuration) or gloo "
@@ -223,85 +225,48 @@ def main():
     scene = rt.Scene(scene_desc)  # BVH build + upload: outside the timed region (scene resident in HBM)
     t_create = time.perf_counter() - t_create
     W, H = args.width, args.height
-    # Frames are independent, so F of them are kept in flight: slot s = step % F has its own non-default HIP stream, ray
-    # queues (inside the library, per stream) and slice / gather / frame buffers.  Within a slot, kernels, events, the RCCL
-    # gather and the de-interleave are ordered on the slot's stream; across slots the tail of one frame's traversal (a few
-    # long rays) overlaps the bulk of the next frame's.  Collectives are issued by this one thread in step order on
-    # every rank.
-    F = max(1, args.frames_in_flight)
-    streams = [torch.cuda.Stream(dev) for _ in range(F)]
+    # Frames are independent and a frame (or a rank's share of one) is a small launch whose persistent traversal kernel
+    # ends with a tail of its longest rays, so B frames are rendered per call (rt_render_frames_device: the rays of the B
+    # frames share the queues and one tail) into the B slices of a set, and the set travels to rank 0 in ONE exchange
+    # (rt_gather_frames: at 8 ranks a rank's share of a frame is 0.78 MB, so a message per frame would be bound by its launch
+    # and host cost).  S sets alternate, each on a HIP stream of its own (kernels and the exchange of a set are ordered on
+    # its stream), so the next B frames render while the previous exchange is in flight; this one thread issues everything in
+    # step order on every rank.  --frames-in-flight F selects the round-1 setting instead: one frame per call on F streams.
+    B, S = max(1, args.frames_per_launch), max(1, args.launches_in_flight)
+    if args.frames_in_flight is not None:
+        B, S = 1, max(1, args.frames_in_flight)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)   # RT_N_COUNTERS
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # Several ranks: a rank's share of a frame is small (0.78 MB and ~0.12 ms of rendering at 8 ranks), so one collective per
-    # frame would be bound by its launch and host cost.  The slices of F consecutive steps travel in ONE gather instead
-    # (FrameGather(frames=F)), issued on a stream of its own once the F renders have finished; two such sets alternate, so
-    # the next F steps render while the gather of the previous F is in flight, and a set is written again only after its
-    # gather has read it (events both ways).  --gather-per-frame keeps one gather per step on the step's stream.
-    batched = world > 1 and not args.gather_per_frame
-    if batched:
-        sets = [FrameGather(W, H, args.tile_rows, dev, frames=F) for _ in range(2)]
-        gather_stream = torch.cuda.Stream(dev)
-        ready = [[torch.cuda.Event() for _ in range(F)] for _ in range(2)]
-        done = [None, None]
-        issued = [0]   # steps issued so far: step j writes slices[j % F] of set (j // F) % 2
-    else:
-        gathers = [FrameGather(W, H, args.tile_rows, dev) for _ in range(F)]   # slice, gather buffers, de-interleave index (rank 0)
+    sets = [FrameGather(W, H, args.tile_rows, dev, frames=B) for _ in range(S)]   # slices [B, max_rows, W, 3]; frames on rank 0
+    batch_events = []
 
-    def flush():
-        """Batched gather of the steps issued since the last one (a full set, or a partial one, which is then closed).
-        Collective: every rank calls it at the same steps.  Returns the set gathered last."""
-        j = issued[0]
-        pending = j - flush.upto
-        if pending == 0:
-            return flush.last
-        s = ((j - 1) // F) % 2
-        for b in range(pending):
-            gather_stream.wait_event(ready[s][b])
-        with torch.cuda.stream(gather_stream):
-            sets[s].run()   # RCCL gather of [F, max_rows, W, 3] per rank to rank 0 + one de-interleave of the F frames
-            done[s] = torch.cuda.Event()
-            done[s].record(gather_stream)
-        issued[0] = flush.upto = (j + F - 1) // F * F   # the next step starts the other set
-        flush.last = sets[s]
-        return flush.last
-    flush.upto, flush.last = 0, None
-
-    def step(i=None, collect=False, slot=None):
-        if batched:
-            j = issued[0]
-            b, s = j % F, (j // F) % 2
-            stream = streams[b if slot is None else slot]
-            with torch.cuda.stream(stream):
-                if done[s] is not None:
-                    stream.wait_event(done[s])   # the set's previous gather has read the slices
-                if i is not None:
-                    ev[i][0].record(stream)
-                scene.render_device(params, sets[s].slices[b].data_ptr(), counters.data_ptr() if collect else None,
-                                    collect_counters=collect, stream=stream.cuda_stream)
-                if i is not None:
-                    ev[i][1].record(stream)
-                ready[s][b].record(stream)
-            issued[0] = j + 1
-            if b == F - 1:
-                flush()
-            return
-        if slot is None:
-            slot = 0 if i is None else i % F
-        stream, fg = streams[slot], gathers[slot]
+    def launch(k, nb=None, collect=False, timed=False):
+        """Batch k: nb (default B) frames into set k % S and the set's exchange.  Collective: every rank issues the same batches."""
+        stream, fg = streams[k % S], sets[k % S]
         with torch.cuda.stream(stream):
-            if i is not None:
-                ev[i][0].record(stream)
-            scene.render_device(params, fg.slice.data_ptr(), counters.data_ptr() if collect else None, collect_counters=collect,
-                                stream=stream.cuda_stream)
-            if i is not None:
-                ev[i][1].record(stream)
-            fg.run()   # RCCL gather of the u8 slices to rank 0 + de-interleave (no-op for one GPU: the slice is the frame)
+            if timed:
+                batch_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nb or B))
+                batch_events[-1][0].record(stream)
+            if collect or B == 1:
+                scene.render_device(params, fg.slices.data_ptr(), counters.data_ptr() if collect else None, collect_counters=collect,
+                                    stream=stream.cuda_stream)
+            else:
+                scene.render_frames_device(params, nb or B, fg.slices.data_ptr(), slice_rows=fg.max_rows, stream=stream.cuda_stream)
+            if timed:
+                batch_events[-1][1].record(stream)
+            fg.run()   # RCCL send/recv of the set's slices to rank 0 + k_deinterleave (one GPU: the slices are the frames)
+
+    def run(frames, timed=False, first_batch=0):
+        i, k = 0, first_batch
+        while i < frames:
+            nb = min(B, frames - i)
+            launch(k, nb, timed=timed)
+            i, k = i + nb, k + 1
+        return k
 
     # one untimed counting pass: rays, box tests, primitive tests per frame of this rank
     counters.zero_()
-    step(collect=True)
-    if batched:
-        flush()
+    launch(0, collect=True)
     torch.cuda.synchronize(dev)
     c = counters.cpu().numpy().astype(np.int64)
     if world > 1:
@@ -313,23 +278,17 @@ def main():
     rays_frame, boxes_frame, prims_frame, nodes_frame = int(c_all[0]), int(c_all[1]), int(c_all[2]), int(c_all[4])
     rays_rank, prims_rank, nodes_rank = int(c[0]), int(c[2]), int(c[4])
 
-    for w in range(args.warmup):
-        for slot in range(F):   # every slot allocates its queues and RCCL warms up
-            step(slot=slot)
-        if batched:
-            flush()
+    # warm-up: at least W frames and at least one batch per set (every stream allocates its queues, RCCL warms up)
+    k0 = run(max(args.warmup, B * S))
     torch.cuda.synchronize(dev)
-    for s in streams:
-        scene.traverse_time(s.cuda_stream)   # drop the warm-up launches from the kernel timing
+    for st in streams:
+        scene.traverse_time(st.cuda_stream)   # drop the warm-up launches from the kernel timing
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if batched:
-        flush()   # the last, possibly partial, set
-    t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (launches + collectives), before waiting for the GPU
+    run(args.steps, timed=True, first_batch=k0)
+    t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (launches + exchanges), before waiting for the GPU
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -339,32 +298,27 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    render_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0   # latency of one frame's kernels
+    # time from the first kernel of a frame's batch to its last (the frame is complete when its batch is)
+    render_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in batch_events])) if batch_events else 0.0
     # device time of the k_traverse launches of the timed region (hipEvents recorded by the library on the launch streams):
-    # with several frames in flight the launches overlap and share the GPU, so each one lasts longer than it would alone
-    tt = [scene.traverse_time(s.cuda_stream) for s in streams]
+    # launches in flight on several streams overlap and share the GPU, so each one lasts longer than it would alone
+    tt = [scene.traverse_time(st.cuda_stream) for st in streams]
     launches = sum(n for _, n in tt)
     traverse_ms_in_flight = sum(ms for ms, _ in tt) / max(1, launches)
-    # roofline pass: the same frames one at a time on one stream (no barrier needed: ranks render independently), so that a
+    # roofline pass: the same batches one at a time on one stream (no barrier needed: ranks render independently), so that a
     # launch's duration is the kernel's own; this is what `rocprofv3 --kernel-trace --stats -- python3 bench.py
-    # --frames-in-flight 1` reports too
-    if F > 1:
-        for i in range(max(3, min(args.steps, 10))):
-            step(slot=0)
-            if batched:
-                flush()
-            torch.cuda.synchronize(dev)
-        ms, launches_alone = scene.traverse_time(streams[0].cuda_stream)
-        traverse_ms = ms / max(1, launches_alone)
-    else:
-        traverse_ms, launches_alone = traverse_ms_in_flight, launches
+    # --launches-in-flight 1` reports too
+    for i in range(3 if B > 1 else max(3, min(args.steps, 10))):
+        launch(0)
+        torch.cuda.synchronize(dev)
+    ms, launches_alone = scene.traverse_time(streams[0].cuda_stream)
+    traverse_ms = ms / max(1, launches_alone)
     if world > 1:
         dist.barrier()
-    # outside the timed region: the frame assembled from the ranks' slices against the same frame rendered whole on rank 0
+    # outside the timed region: the frames assembled from the ranks' slices against the same frame rendered whole on rank 0
     frame_ok = None
     if world > 1:
-        step(slot=0)
-        last = flush() if batched else gathers[0]
+        launch(0)
         torch.cuda.synchronize(dev)
         if rank == 0:
             whole = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
@@ -372,20 +326,24 @@ def main():
             p1.part_count, p1.part_index = 1, 0
             scene.render_device(p1, whole.data_ptr(), stream=streams[0].cuda_stream)
             torch.cuda.synchronize(dev)
-            frame_ok = bool(torch.equal(whole, last.frame))
+            frame_ok = all(bool(torch.equal(whole, sets[0].frames[b])) for b in range(B))
         dist.barrier()
 
     # one frame at a time (latency setting) and the boundary's own contract -- rt_render into a HOST buffer (main.cpp:242,320)
-    solo_ms, host_ms = None, None
+    solo_ms, host_ms, traverse_ms_one_frame = None, None, None
     if world == 1:
         torch.cuda.synchronize(dev)
         n_solo = max(5, min(args.steps, 20))
+        scene.render_device(params, sets[0].slices.data_ptr(), stream=streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        scene.traverse_time(streams[0].cuda_stream)
         t1 = time.perf_counter()
         for _ in range(n_solo):
-            step(slot=0)
+            scene.render_device(params, sets[0].slices.data_ptr(), stream=streams[0].cuda_stream)
             torch.cuda.synchronize(dev)
         solo_ms = (time.perf_counter() - t1) * 1e3 / n_solo
-        scene.traverse_time(streams[0].cuda_stream)
+        ms, n1 = scene.traverse_time(streams[0].cuda_stream)
+        traverse_ms_one_frame = ms / max(1, n1)
         p_host = params.copy()
         p_host.part_count, p_host.part_index = 1, 0
         scene.render(p_host)
@@ -398,9 +356,10 @@ def main():
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         value = rays_frame * args.steps / elapsed / 1e6
         boxes_rank = int(c[1])
-        alg_bytes = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES_LAYOUT + rays_rank * RAY_STATE_BYTES
-        alg_bytes_survey = nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES_SURVEY + rays_rank * RAY_STATE_BYTES
-        alg_flops = boxes_rank * FLOPS_PER_BOX_TEST + prims_rank * FLOPS_PER_SPHERE_TEST
+        # per launch of the dominant kernel = B frames of this rank
+        alg_bytes = B * (nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES_LAYOUT + rays_rank * RAY_STATE_BYTES)
+        alg_bytes_survey = B * (nodes_rank * NODE_BYTES + prims_rank * SPHERE_BYTES_SURVEY + rays_rank * RAY_STATE_BYTES)
+        alg_flops = B * (boxes_rank * FLOPS_PER_BOX_TEST + prims_rank * FLOPS_PER_SPHERE_TEST)
         kt = traverse_ms * 1e-3
         # What bounds k_traverse is VALU issue under divergence, not memory (the hierarchy is served by L2 / Infinity Cache:
         # measured HBM traffic is ~6 % of the algorithmic bytes).  The instruction and active-lane counts of a launch are fixed
@@ -412,11 +371,15 @@ def main():
             try:
                 t = json.load(open(tp))
                 if t.get("spheres") == args.spheres and t.get("n_gpus", 1) == world and (args.width, args.height) == (1920, 1080):
-                    pmc = t
+                    if B == 1:
+                        pmc = t
+                    elif t.get("batch", {}).get("frames_per_launch") == B:   # counters of a launch of B frames
+                        pmc = dict(t["batch"], build=t.get("build"), collected=t.get("collected"))
             except Exception:
                 pmc = None
-        roof = {"bound": "valu", "kernel": "k_traverse", "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches_alone,
+        roof = {"bound": "valu", "kernel": "k_traverse", "frames_per_launch": B, "kernel_ms": round(traverse_ms, 4), "kernel_launches": launches_alone,
                 "kernel_ms_in_flight": round(traverse_ms_in_flight, 4), "kernel_launches_in_flight": launches,
+                "kernel_ms_one_frame_per_launch": round(traverse_ms_one_frame, 4) if traverse_ms_one_frame else None,
                 "unit": "Tlane-op/s", "peak": round(VALU_PEAK_TLANEOPS, 2), "achieved": None, "frac": None, "traffic": None,
                 "algorithmic": {"flops_per_launch": alg_flops, "TFLOP_per_s": round(alg_flops / kt / 1e12, 3) if kt > 0 else None,
                                 "frac_of_fp32_vector_peak": round(alg_flops / kt / 1e12 / VALU_PEAK_FP32_TFLOPS, 5) if kt > 0 else None,
@@ -450,7 +413,8 @@ def main():
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
-                       "frames_in_flight": F, "frames_per_gather": (F if batched else 1) if world > 1 else None, "scene_create_ms": round(t_create * 1e3, 1),
+                       "frames_per_launch": B, "launches_in_flight": S, "frames_in_flight": B * S,
+                       "frames_per_exchange": B if world > 1 else None, "scene_create_ms": round(t_create * 1e3, 1),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rays_per_lane": os.environ.get("RT_RAYS_PER_LANE"),
                        "gathered_frame_equals_whole_frame": frame_ok},
             "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),

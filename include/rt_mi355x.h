@@ -288,6 +288,17 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);
 
+/* `frames` frames of the same scene and the same part in one set of launches (the pixel loop of main.cpp:281-322 run
+ * `frames` times: successive frames of a throughput run, or passes of a progressive render; frame f uses seed
+ * params->seed + f, so in RT_RNG_D0 mode all frames are equal).  d_rgb8 receives the frames' slices one after another,
+ * slice_rows rows of W*3 bytes apart (slice_rows >= rt_part_rows(); 0 = rt_part_rows(): the padded equal slices a gather
+ * over ranks wants are written in place); each slice holds what rt_render_device writes.  Why: the persistent traversal kernel ends with a tail of
+ * its longest rays that does not shrink with the launch, and a rank's share of a frame on an 8-GPU node is small; the
+ * rays of all frames share one queue (8-row bands of the frames alternate, so every XCD still works on one region of
+ * the image) and one tail.  Wavefront schedule only.  d_counters as in rt_render_device (sums over the frames). */
+int rt_render_frames_device(rt_scene_t scene, const RtRenderParams* params, int frames, int slice_rows, void* d_rgb8,
+                            void* d_counters, void* hip_stream);
+
 /* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  It has NO counterpart in the reference (which has no device): same pixels as
  * rt_render_device with the wavefront schedule, but every buffer the kernels need beyond the scene and d_rgb8 -- ray

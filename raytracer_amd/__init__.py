@@ -118,7 +118,7 @@ ABI_SYMBOLS = [
     "rt_params_from_config", "rt_scene_file_load", "rt_scene_file_parse", "rt_scene_file_desc",
     "rt_scene_file_destroy", "rt_shapes_from_trs", "rt_write_ppm", "rt_read_ppm", "rt_read_pfm", "rt_free",
     "rt_version", "rt_traverse_time", "rt_bvh_device_image", "rt_render_linear", "rt_render_linear_device", "rt_write_pfm",
-    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_render_device_noalloc", "rt_reserve",
+    "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_render_device_noalloc", "rt_render_frames_device", "rt_reserve",
     "rt_release_workspaces", "rt_comm_unique_id", "rt_comm_init", "rt_comm_rank", "rt_comm_world", "rt_comm_destroy",
     "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered", "rt_accumulate_device", "rt_resolve_sum_device",
 ]
@@ -169,6 +169,7 @@ def _load():
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
         "rt_render_device_noalloc": (i32, [vp, C.POINTER(RtRenderParams), vp, vp]),
+        "rt_render_frames_device": (i32, [vp, C.POINTER(RtRenderParams), i32, i32, vp, vp, vp]),
         "rt_reserve": (i32, [vp, C.c_uint64, i32]), "rt_release_workspaces": (i32, []),
         "rt_comm_unique_id": (i32, [vp]), "rt_comm_init": (i32, [i32, i32, vp]), "rt_comm_rank": (i32, []),
         "rt_comm_world": (i32, []), "rt_comm_destroy": (i32, []),
@@ -539,6 +540,11 @@ class Scene:
     def accumulate_device(self, params, d_sum_ptr, first_pass, passes, stream=None):
         """Add `passes` passes (seeds params.seed + first_pass ...) to the FP64 sum in device memory (rt_accumulate_device)."""
         _check(lib.rt_accumulate_device(self._h, C.byref(params), d_sum_ptr, int(first_pass), int(passes), stream))
+
+    def render_frames_device(self, params, frames, d_rgb8_ptr, slice_rows=0, d_counters_ptr=None, stream=None):
+        """`frames` frames (seeds params.seed + f) of this part in one set of launches; slices `slice_rows` rows apart
+        (0 = rt_part_rows) in device memory (see rt_render_frames_device)."""
+        _check(lib.rt_render_frames_device(self._h, C.byref(params), int(frames), int(slice_rows), d_rgb8_ptr, d_counters_ptr, stream))
 
     def render_device_noalloc(self, params, d_rgb8_ptr, stream=None):
         """rt_render_device through the library's static workspace: no device allocation (see rt_render_device_noalloc)."""

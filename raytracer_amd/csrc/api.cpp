@@ -688,6 +688,7 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     d.tile_rows = tile; d.part_index = parts > 1 ? p->part_index : 0; d.part_count = parts;
     d.part_rows = rt_part_rows(scene->height, tile, d.part_index, parts);
     d.count_tests = collect ? 1 : 0;
+    d.frames = 1; d.slice_rows = d.part_rows;
     d.exposure = p->exposure; d.eps_scene = p->eps_scene; d.eps_triangle = p->eps_triangle; d.eps_march = p->eps_march;
     d.eps_shadow = p->eps_shadow; d.step_multiplier = p->step_multiplier;
     std::memcpy(d.background, p->background, 24);
@@ -714,6 +715,33 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     else
         e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
                                     *workspace_of(st, true));
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+// Several frames of one scene in one set of launches: a frame's share of the work on one of many GPUs is small, and a small
+// launch of the persistent traversal kernel spends most of its time in the tail of its longest rays; F frames in one
+// launch have one tail.  Frame f is rendered with seed + f (progressive passes, or the frames of a throughput benchmark).
+int rt_render_frames_device(rt_scene_t scene, const RtRenderParams* params, int frames, int slice_rows, void* d_rgb8, void* d_counters,
+                            void* hip_stream) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!d_rgb8) return fail(RT_ERR_INVALID, "d_rgb8 is NULL");
+    if (frames < 1 || frames > 4096) return fail(RT_ERR_INVALID, "frames must be 1 .. 4096");
+    DParams dp;
+    int rc = make_dparams(scene, params, 0, &dp);
+    if (rc) return rc;
+    if (params->schedule != RT_SCHEDULE_WAVEFRONT) return fail(RT_ERR_INVALID, "rt_render_frames_device renders with the wavefront schedule");
+    if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
+    if (slice_rows == 0) slice_rows = dp.part_rows;
+    if (slice_rows < dp.part_rows) return fail(RT_ERR_INVALID, "slice_rows is smaller than the rows this part owns (rt_part_rows)");
+    if (dp.part_rows == 0) return RT_OK;
+    if (static_cast<long long>(frames) * slice_rows * dp.width >= (1ll << 31))
+        return fail(RT_ERR_LIMIT, "frames x slice_rows x width must stay below 2^31 pixels per call");
+    dp.frames = frames;
+    dp.slice_rows = slice_rows;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipError_t e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
+                                           *workspace_of(st, true));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }

@@ -162,6 +162,9 @@ struct DParams {
     int32_t tile_rows, part_index, part_count, part_rows;  // part_rows = rows this part owns
     int32_t count_tests;   // also count node / primitive tests
     int32_t pad;
+    // Several frames of the same scene in one launch (rt_render_frames_device): frame f is rendered with seed + f into the
+    // slice that begins f * slice_rows rows into the output.  frames = 1, slice_rows = part_rows for every other entry point.
+    int32_t frames, slice_rows;
     double exposure, eps_scene, eps_triangle, eps_march, eps_shadow, step_multiplier;
     double background[3];
     double ambient_light[3];

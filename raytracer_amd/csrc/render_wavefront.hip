@@ -64,10 +64,21 @@ static_assert(sizeof(HitRec) == 32, "HitRec size");
 // capacity): consecutive lanes work on consecutive records, so every load / store instruction of a wave covers 1 KB of
 // contiguous memory instead of 64 pieces 112 bytes apart.
 typedef unsigned rt_q4 __attribute__((ext_vector_type(4)));
+struct Chunk {
+    int row0, rows;     // rows [row0, row0 + rows) of the launch (compact rows of this part; frame after frame or band by band, k_raygen)
+    int s0, ns;         // samples [s0, s0 + ns) of every pixel
+};
+// Primary rays (the queue k_raygen writes: level 0 of every ray tree) are stored SLIM: pieces 0..2 as in RayRec (origin,
+// direction) and piece 3 = (time, rng), 64 bytes instead of 112.  The rest of a primary ray's record is implied -- weight 1,
+// tmax 100000, depth max_depth, kind radiance -- or follows from its index in the queue (pixel: primary_coords), so the
+// three passes over the primary rays (written by k_raygen, read by traversal and by shading) move 144 bytes less per ray.
 struct RayQ {
     rt_q4* p;
     unsigned stride;
+    unsigned primary;   // 1: slim primary records of chunk `ck`
+    Chunk ck;
 };
+__device__ __host__ __forceinline__ RayQ rebase(const RayQ& q, unsigned origin) { return RayQ{q.p + origin, q.stride, q.primary, q.ck}; }
 struct HitQ {
     rt_q4* p;
     unsigned stride;
@@ -82,7 +93,7 @@ union HitBits {
     rt_q4 v[2];
     __device__ HitBits() {}
 };
-__device__ __forceinline__ RayRec ray_load(const RayQ q, unsigned i) {
+__device__ __forceinline__ RayRec ray_load_full(const RayQ& q, unsigned i) {
     RayBits b;
 #pragma unroll
     for (int k = 0; k < 7; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
@@ -144,10 +155,6 @@ __device__ __forceinline__ void bundle_store(const BundleQ q, unsigned i, const 
     for (int k = 0; k < 8; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
 }
 
-struct Chunk {
-    int row0, rows;     // compact rows [row0, row0 + rows) of this part
-    int s0, ns;         // samples [s0, s0 + ns) of every pixel
-};
 
 // Sharded queues.  The tail of a queue is a word that every emitting wave adds to with a returning atomic, and one word
 // takes ~88 such atomics per microsecond (MI355X_MICROARCH.md, dequeue row): a frame of small waves of work -- one hit,
@@ -196,7 +203,7 @@ __device__ __forceinline__ unsigned queue_total(const QIn& q) {   // entries in 
 // of 64-byte segments its lanes touch; neighbouring lanes hold neighbouring pixels, and a plane puts their 8-byte sums
 // side by side (8 pixels per request) where interleaved RGB spreads them over three times as many segments.
 __device__ __forceinline__ void accum_add(double* accum, const DParams& P, int pixel, D3 c) {
-    const size_t plane = (size_t)P.part_rows * P.width;
+    const size_t plane = (size_t)P.frames * P.slice_rows * P.width;
     unsafeAtomicAdd(&accum[pixel], c.x);
     unsafeAtomicAdd(&accum[plane + pixel], c.y);
     unsafeAtomicAdd(&accum[2 * plane + pixel], c.z);
@@ -267,33 +274,73 @@ __device__ __forceinline__ void pixel_of(long long pix, int W, int rows, int& x,
     x = tx * 8 + rem % tw;
 }
 
-__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const Chunk ck, const RayQ out, long long n,
+// Index i of a chunk's primary rays -> pixel (x, y) of the frame, sample, frame of the launch, and the pixel's index in the
+// output / the accumulators.  Row of the launch -> (frame, compact row of the part): with several frames the 8-row bands of
+// the frames alternate (band b of every frame, then band b + 1 ...), so that a contiguous share of the queue -- what the
+// waves of one XCD traverse -- covers the same region of the image in all frames; parts whose rows are no multiple of 8 go
+// frame by frame.
+struct PrimaryCoords { int x, y, s, frame, pixel; };
+__device__ __forceinline__ PrimaryCoords primary_coords(const DParams& P, const Chunk& ck, long long i) {
+    PrimaryCoords c;
+    const long long pix = i / ck.ns;
+    c.s = ck.s0 + (int)(i % ck.ns);
+    int ly;
+    pixel_of(pix, P.width, ck.rows, c.x, ly);
+    int lr = ck.row0 + ly;
+    c.frame = 0;
+    if (P.frames > 1) {
+        if ((P.part_rows & 7) == 0) {
+            const int band = lr >> 3;
+            c.frame = band % P.frames;
+            lr = (band / P.frames) * 8 + (lr & 7);
+        } else {
+            c.frame = lr / P.part_rows;
+            lr -= c.frame * P.part_rows;
+        }
+    }
+    c.y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
+    c.pixel = (c.frame * P.slice_rows + lr) * P.width + c.x;
+    return c;
+}
+// A queued ray: a full record, or a slim primary record completed by what is implied.
+__device__ __forceinline__ RayRec ray_load(const RayQ& q, unsigned i, const DParams& P) {
+    if (!q.primary) return ray_load_full(q, i);
+    RayBits b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    RayRec r = b.r;   // o, d in place; w[0], w[1] hold (time, rng)
+    const double time = r.w[0];
+    const unsigned long long rng = (unsigned long long)__double_as_longlong(r.w[1]);
+    r.w[0] = r.w[1] = r.w[2] = 1.0;
+    r.time = time; r.tmax = 100000.0; r.rng = rng;
+    r.pixel = primary_coords(P, q.ck, (long long)i).pixel;
+    r.depth = (short)P.max_depth; r.kind = kKindRadiance;
+    return r;
+}
+
+__global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams P, const RayQ out, long long n,
                                                    unsigned* __restrict__ fetch_counters) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     // the traversal launched next on this stream starts with its queue fetch counters at zero (saves a memset launch)
     if (blockIdx.x == 0 && threadIdx.x < kFetchCounterWords) fetch_counters[threadIdx.x] = 0u;
     if (i >= n) return;
-    const long long pix = i / ck.ns;
-    const int s = ck.s0 + (int)(i % ck.ns);
-    int x, ly;
-    pixel_of(pix, P.width, ck.rows, x, ly);
-    const int lr = ck.row0 + ly;
-    const int y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
+    const PrimaryCoords c = primary_coords(P, out.ck, i);
     Rng rng;  // main.cpp:288-302
     rng.d0 = (P.rng_mode == RT_RNG_D0);
-    rng.s = (P.seed * 0x9E3779B97F4A7C15ull) ^
-            (((unsigned long long)y * P.width + x) * 0xD1B54A32D192ED03ull + (unsigned long long)s * 0x8CB92BA72F3D8DD7ull);
+    rng.s = ((P.seed + (unsigned long long)c.frame) * 0x9E3779B97F4A7C15ull) ^
+            (((unsigned long long)c.y * P.width + c.x) * 0xD1B54A32D192ED03ull + (unsigned long long)c.s * 0x8CB92BA72F3D8DD7ull);
     float ru = (float)rng.uniform(), rv = (float)rng.uniform();
-    float px = ((float)x + ru) / (float)P.width;
-    float py = ((float)y + rv) / (float)P.height;
+    float px = ((float)c.x + ru) / (float)P.width;
+    float py = ((float)c.y + rv) / (float)P.height;
     double time = rng.uniform() * S.shutter_time;
     Ray ray = generate_ray(S.cam, px, py, time, rng);
-    RayRec r;
-    r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z;
-    r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z;
-    r.w[0] = r.w[1] = r.w[2] = 1.0;
-    r.time = time; r.tmax = 100000.0; r.rng = rng.next(); r.pixel = lr * P.width + x; r.depth = (short)P.max_depth; r.kind = kKindRadiance;
-    ray_store(out, (unsigned)i, r);
+    RayBits b;
+    b.r.o[0] = ray.o.x; b.r.o[1] = ray.o.y; b.r.o[2] = ray.o.z;
+    b.r.d[0] = ray.d.x; b.r.d[1] = ray.d.y; b.r.d[2] = ray.d.z;
+    b.r.w[0] = time;                                      // slim record: piece 3 = (time, rng)
+    b.r.w[1] = __longlong_as_double((long long)rng.next());
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out.p[(size_t)k * out.stride + (unsigned)i] = b.v[k];
 }
 
 // ------------------------------------------------------------------------------------------ k_traverse
@@ -398,7 +445,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
             const unsigned take = min((unsigned)__popcll(idle), avail);
             if (my == kNone && rank < take) {
                 my = chunk_next + rank;
-                const RayRec q = ray_load(rays, my);
+                const RayRec q = ray_load(rays, my, P);
                 r.o = ld3(q.o);
                 r.d = ld3(q.d);
                 r.time = q.time;
@@ -766,7 +813,7 @@ __global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S
     if (span.begin >= span.end) return;
     const DScene S = staged.stage(S0);
     const int lane = threadIdx.x & 63;
-    const RayQ rays{rays_all.p + span.origin, rays_all.stride};
+    const RayQ rays = rebase(rays_all, span.origin);
     const HitQ hits{hits_all.p + span.origin, hits_all.stride};
     // The host sizes the grid by the count when it knows it, and by the machine when the count is on the device (a level
     // enqueued without a round trip: its bound is often orders of magnitude above what is really there, and a hundred
@@ -778,7 +825,7 @@ __global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S
         D3 c = mk(0.0, 0.0, 0.0);
         int pixel = -1 - lane;   // lanes without a contribution: a run of their own
         if (i < span.end) {
-            const RayRec q = ray_load(rays, i);
+            const RayRec q = ray_load(rays, i, P);
             const HitRec hr = hit_load(hits, i);
             D3 contrib = mk(0.0, 0.0, 0.0);
             if (shade_ray<F, EMIT>(S, P, q, hr, Ew, contrib)) {
@@ -957,7 +1004,7 @@ k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const Hi
     const BlockSpan span = block_span(in);
     if (span.begin >= span.end) return;   // (whole workgroup: before the barrier of the staging)
     const DScene S = stage_small_scene(S0, small_lds);
-    const RayQ rays{rays_all.p + span.origin, rays_all.stride};
+    const RayQ rays = rebase(rays_all, span.origin);
     const HitQ hits{hits_all.p + span.origin, hits_all.stride};
     const unsigned n = span.end;
     const int lane = threadIdx.x & 63;
@@ -969,7 +1016,7 @@ k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const Hi
         double tmin = 0.0, tmax = 0.0;
         bool shadow = false;
         if (mine) {
-            const RayRec q = ray_load(rays, i);
+            const RayRec q = ray_load(rays, i, P);
             r.o = ld3(q.o);
             r.d = ld3(q.d);
             r.time = q.time;
@@ -1073,7 +1120,9 @@ struct Driver {
         if (e != hipSuccess && err == hipSuccess) err = e;
         return err == hipSuccess;
     }
-    RayQ rays(int q) { return RayQ{static_cast<rt_q4*>(ws.queues[q]), (unsigned)ws.capacity}; }
+    Chunk chunk{0, 0, 0, 1};   // the chunk of primary rays being rendered
+    // queue q as the kernels see it: level 0 holds the slim primary records of `chunk`, deeper levels full records
+    RayQ rays(int q, int level = 1) { return RayQ{static_cast<rt_q4*>(ws.queues[q]), (unsigned)ws.capacity, level == 0 ? 1u : 0u, chunk}; }
     HitQ hits(int q) { return HitQ{static_cast<rt_q4*>(ws.hit_buffers[q]), (unsigned)ws.capacity}; }
 
     int acquire() {
@@ -1125,19 +1174,19 @@ struct Driver {
         return (unsigned)std::max<unsigned long long>(k, (blocks + k - 1) / k * k);
     }
 
-    template <int F> void launch_traverse(int q, const QIn& in, unsigned bound) {
+    template <int F> void launch_traverse(int q, const QIn& in, unsigned bound, int level) {
         const bool timed = !ws.fixed && ws.events_used + 2 <= kMaxTimedEvents;
         hipEvent_t e0 = timed ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
         if (e1) (void)hipEventRecord(e0, stream);
-        launch_traverse_kernel<F>(q, in, bound);
+        launch_traverse_kernel<F>(q, in, bound, level);
         if (e1) (void)hipEventRecord(e1, stream);
         else if (e0) --ws.events_used;   // keep start/stop pairs whole
     }
-    template <int F> void launch_traverse_kernel(int q, const QIn& in, unsigned bound) {
+    template <int F> void launch_traverse_kernel(int q, const QIn& in, unsigned bound, int level) {
         unsigned long long* level_total = reinterpret_cast<unsigned long long*>(ws.counters + kLevelTotal);
         if (small_scene()) {
             const unsigned blocks = in.counts ? grid_for(in, bound) : std::max(1u, std::min((bound + kBlock - 1) / kBlock, (unsigned)ws.compute_units * 16u));
-            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), in, ws.stats, level_total, zero_a, zero_b, K);
+            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), in, ws.stats, level_total, zero_a, zero_b, K);
             zero_a = zero_b = nullptr;
             return;
         }
@@ -1150,10 +1199,10 @@ struct Driver {
         const unsigned want = (n + per_block - 1) / per_block;
         const unsigned blocks = std::max(1u, std::min((unsigned)traverse_blocks, want));
         if (P.count_tests)
-            hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
+            hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), n, n_device, per_block,
                                ws.counters + kNextBase, ws.stats, level_total);
         else
-            hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q), hits(q), n, n_device, per_block,
+            hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), n, n_device, per_block,
                                ws.counters + kNextBase, ws.stats, level_total);
     }
     unsigned *zero_a = nullptr, *zero_b = nullptr;   // tails the next small-scene traversal launch zeroes (run_levels)
@@ -1163,7 +1212,7 @@ struct Driver {
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && getenv("RT_NO_SMALL_SCENE") == nullptr; }
     // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
     EmitCtx emit_ctx(int qo, int out_level) {
-        return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u}, tails(out_level), ws.counters + 2, qo >= 0 ? region() : 0u, direct,
+        return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u, 0u, chunk}, tails(out_level), ws.counters + 2, qo >= 0 ? region() : 0u, direct,
                        BundleQ{static_cast<rt_q4*>(ws.bundles), (unsigned)ws.capacity}, bundle_tails(), ws.bundles ? region() : 0u, K};
     }
     // The shadow rays of the hits a shading launch of at most n rays has just bundled (at most n x lights bundles).
@@ -1184,22 +1233,23 @@ struct Driver {
         else launch_shadow<kFull>(n, qo, out_level);
     }
     template <int F> void launch_shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
+        const int level = out_level - 1;
         const EmitCtx E = emit_ctx(qo, out_level);
         const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi)));
         const QIn& v = in;
         if (may_emit && small_scene())
-            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
         else if (may_emit)
-            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
         else if (small_scene())
-            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
         else
-            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
     }
-    void traverse(int q, const QIn& in, unsigned bound) {
-        if (variant == 0) launch_traverse<kSpheres>(q, in, bound);
-        else if (variant == 1) launch_traverse<kAnalytic>(q, in, bound);
-        else launch_traverse<kFull>(q, in, bound);
+    void traverse(int q, const QIn& in, unsigned bound, int level) {
+        if (variant == 0) launch_traverse<kSpheres>(q, in, bound, level);
+        else if (variant == 1) launch_traverse<kAnalytic>(q, in, bound, level);
+        else launch_traverse<kFull>(q, in, bound, level);
     }
     void shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
         if (variant == 0) launch_shade<kSpheres>(q, in, bound, qo, out_level);
@@ -1229,7 +1279,7 @@ struct Driver {
             const bool small = small_scene();
             if (small) { zero_a = tails(level + 1); zero_b = bundle_tails(); }   // k_traverse_small zeroes them itself
             else if (level > 0 && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) break;
-            traverse(q, in, n);
+            traverse(q, in, n, level);
             const int qo = acquire();
             if (qo < 0) break;
             if (!small && !ok(hipMemsetAsync(tails(level + 1), 0, tails_bytes(), stream))) { release(qo); break; }
@@ -1287,7 +1337,7 @@ struct Driver {
         const bool is_dense = level == 0 || K == 1;
         // level 0: k_raygen has zeroed the fetch counters
         if (level > 0 && !small_scene() && !ok(hipMemsetAsync(ws.counters + kNextBase, 0, kFetchCounterWords * sizeof(unsigned), stream))) { release(q); return; }
-        traverse(q, is_dense ? dense(n) : sharded(level), n);
+        traverse(q, is_dense ? dense(n) : sharded(level), n, level);
         rays_traced += n;
         if (!may_emit) {   // no material spawns rays and shadows are off: shade and return, nothing to read back (asynchronous)
             shade(q, dense(n), n, -1, level + 1);
@@ -1474,8 +1524,10 @@ hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, si
 
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
                                    hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, bool add_linear) {
-    const size_t npix = (size_t)params.part_rows * params.width;
-    if (npix == 0) return hipSuccess;
+    // pixels of the output: `frames` slices of slice_rows rows each (one frame of part_rows rows unless rt_render_frames_device calls)
+    const size_t npix = (size_t)params.frames * params.slice_rows * params.width;
+    const int launch_rows = params.frames * params.part_rows;   // rows of primary rays
+    if (npix == 0 || launch_rows == 0) return hipSuccess;
     hipError_t e;
     const bool may_emit = frame_may_emit(scene, params);
     size_t max_queue_rays = ws.capacity;
@@ -1495,6 +1547,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
     // persistent traversal grid: at most RT_TRAVERSE_WAVES waves per SIMD on every CU (LDS: 34 KB per 256-thread block)
     D.traverse_blocks = ws.compute_units * RT_TRAVERSE_WAVES;
+    if (const char* tb = getenv("RT_TRAVERSE_BLOCKS_PER_CU")) D.traverse_blocks = ws.compute_units * std::max(1, atoi(tb));
 
     // Primary rays are generated in chunks of whole 8-row bands x a batch of samples, sized so that the first
     // level's children always fit one queue.
@@ -1506,7 +1559,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     const size_t max_primary = std::max<size_t>(64, ws.capacity / fo0 > slack + 64 ? ws.capacity / fo0 - slack : 64);
     const int W = params.width;
     int ns = (int)std::min<size_t>((size_t)params.spp, std::max<size_t>(1, max_primary / ((size_t)W * 8)));
-    int rows_per_chunk = (int)std::min<size_t>((size_t)params.part_rows, std::max<size_t>(8, (max_primary / ((size_t)W * ns)) / 8 * 8));
+    int rows_per_chunk = (int)std::min<size_t>((size_t)launch_rows, std::max<size_t>(8, (max_primary / ((size_t)W * ns)) / 8 * 8));
     if ((size_t)rows_per_chunk * W * ns > ws.capacity) return hipErrorInvalidValue;  // frame wider than the queue: raise RT_QUEUE_RAYS
     // A frame is first tried without host round trips between the levels of its ray tree: every chunk of primary rays
     // enqueues all its levels and is read back once (Driver::run_levels).  A level that outgrows a queue shard makes the
@@ -1514,18 +1567,19 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     // counters and the traversal timing is dropped), and the stream's later frames of that scene go that way at once.
     // RT_SYNC_LEVELS=1 keeps the level-by-level path (A/B runs, tests).
     const int levels = tree_levels(scene, params);
-    D.allow_grow = rows_per_chunk >= params.part_rows && ns >= params.spp;
+    D.allow_grow = rows_per_chunk >= launch_rows && ns >= params.spp;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool optimistic = attempt == 0 && may_emit && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
         bool overflowed = false;
-        for (int row0 = 0; row0 < params.part_rows && D.err == hipSuccess && !overflowed; row0 += rows_per_chunk) {
-            const int rows = std::min(rows_per_chunk, params.part_rows - row0);
+        for (int row0 = 0; row0 < launch_rows && D.err == hipSuccess && !overflowed; row0 += rows_per_chunk) {
+            const int rows = std::min(rows_per_chunk, launch_rows - row0);
             for (int s0 = 0; s0 < params.spp && D.err == hipSuccess && !overflowed; s0 += ns) {
                 Chunk ck{row0, rows, s0, std::min(ns, params.spp - s0)};
                 const long long n = (long long)rows * W * ck.ns;
                 int q = D.acquire();
                 if (q < 0) break;
-                hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, ck, D.rays(q), n,
+                D.chunk = ck;
+                hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, D.rays(q, 0), n,
                                    ws.counters + kNextBase);
                 if (optimistic) {
                     const int lr = D.run_levels(q, (unsigned)n, levels);

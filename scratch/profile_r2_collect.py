@@ -8,7 +8,7 @@ src = "gpurun_out/prof_%s" % tag
 build = os.environ.get("RT_BUILD_ID") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 dst = os.environ.get("RT_PROFILE_OUT", "profiles")
 os.makedirs(dst, exist_ok=True)
-for f in ("c2_kernel_stats_1inflight.csv", "c2_kernel_stats_8inflight.csv", "bench_1inflight.json", "bench_8inflight.json"):
+for f in ("c2_kernel_stats_1inflight.csv", "c2_kernel_stats_default.csv", "c2_kernel_stats_batch16.csv", "bench_1inflight.json", "bench_default.json", "batch16.txt"):
     shutil.copy(os.path.join(src, f), "%s/%s_%s" % (dst, rnd, f))
 
 def kname(k):
@@ -47,6 +47,29 @@ out = {"kernel": "k_traverse", "spheres": 1000000, "n_gpus": 1, "build": build, 
                  "MI355X_MICROARCH.md), writes = WRITE_SIZE*1024; active lanes = SQ_THREAD_CYCLES_VALU / (64*SQ_INSTS_VALU); "
                  "issue fraction = SQ_INSTS_VALU*4 cycles / (1024 SIMDs * 2.4 GHz * kernel time)",
        "source": "profiles/%s_c2_pmc_summary.txt, profiles/%s_c2_kernel_stats_1inflight.csv" % (rnd, rnd)}
+
+def digest(t, kt):
+    read_b = 128 * t.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * t.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * t.get("TCC_EA0_RDREQ_32B_sum", 0)
+    write_b = t.get("WRITE_SIZE", 0) * 1024
+    return {"kernel_ms_in_trace": round(kt * 1e3, 4), "hbm_bytes_per_launch": int(read_b + write_b), "hbm_read_bytes": int(read_b),
+            "hbm_write_bytes": int(write_b), "l2_hit_rate": round(t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"]), 4),
+            "valu": {"wave_instructions_per_launch": int(t["SQ_INSTS_VALU"]),
+                     "active_lane_fraction": round(t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_INSTS_VALU"]), 4),
+                     "issue_fraction_in_trace": round(t["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * kt), 4)}}
+
+cb = pmc("pmcb")
+if "k_traverse" in cb:
+    tb = {c: sum(v) / len(v) for c, v in cb["k_traverse"].items()}
+    sb = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "c2_kernel_stats_batch16.csv"))) if kname(r["Name"])}
+    out["batch"] = dict(digest(tb, float(sb["k_traverse"]["AverageNs"]) * 1e-9), frames_per_launch=16,
+                        source="profiles/%s_c2_batch16_pmc_summary.txt, profiles/%s_c2_kernel_stats_batch16.csv" % (rnd, rnd))
+    with open("%s/%s_c2_batch16_pmc_summary.txt" % (dst, rnd), "w") as o:
+        o.write("# rocprofv3 --pmc, one pass per run, scratch/batch_launches.py 16 (launches of 16 C2 frames, one at a time), build %s\n" % build)
+        for k in ("k_raygen", "k_traverse", "k_shade"):
+            if k in cb:
+                o.write("[%s] mean per launch over %d launches\n" % (k, len(next(iter(cb[k].values())))))
+                for c, v in sorted(cb[k].items()):
+                    o.write("  %-36s %.6g\n" % (c, sum(v) / len(v)))
 json.dump(out, open(dst + "/pmc_c2.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 

@@ -87,10 +87,11 @@ def test_rccl_path_with_a_loopback_communicator(gpu, monkeypatch):
 
 def test_bench_starts_its_own_ranks(gpu):
     """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself and reports n_gpus 2 with the gathered frame
-    equal to the frame rendered whole (gloo rehearsal on the one GPU; a small scene, no CPU baseline)."""
+    equal to the frame rendered whole (gloo rehearsal on the one GPU; a small scene, no CPU baseline; batches of 3 frames per
+    launch and exchange, the last batch a partial one)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--spheres", "20000",
-                          "--steps", "3", "--warmup", "1", "--frames-in-flight", "2"], env=env, capture_output=True, text=True, timeout=600)
+                          "--steps", "7", "--warmup", "1", "--frames-per-launch", "3", "--no-configs", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)

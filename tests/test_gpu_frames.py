@@ -1,0 +1,114 @@
+"""GPU tests of rt_render_frames_device: several frames of one scene in one set of launches.  Every slice must hold what
+rt_render_device writes for that frame (seed + f): bit for bit where a pixel gets one ray or the sampling is
+deterministic up to the order of FP64 additions (<= 1 level, as between any two wavefront renders), for frames that queue
+rays and frames that do not, parts of a partitioned frame, padded slices, and part heights that are and are not multiples
+of 8 (the two ways rows of a launch map to frames)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import raytracer_amd as rt
+from raytracer_amd import workloads
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _frames(scene, params, frames, slice_rows=0, stream=None):
+    rows = rt.part_rows(scene.height, params.tile_rows or 8, params.part_index, max(params.part_count, 1))
+    sr = slice_rows or rows
+    out = torch.full((frames, sr, scene.width, 3), 7, dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize(DEV)
+    scene.render_frames_device(params, frames, out.data_ptr(), slice_rows=slice_rows, stream=stream)
+    torch.cuda.synchronize(DEV)
+    return out.cpu().numpy(), rows
+
+
+def _single(scene, params, seed_offset):
+    p = params.copy()
+    p.seed = params.seed + seed_offset
+    rows = rt.part_rows(scene.height, p.tile_rows or 8, p.part_index, max(p.part_count, 1))
+    out = torch.zeros((rows, scene.width, 3), dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize(DEV)
+    scene.render_device(p, out.data_ptr())
+    torch.cuda.synchronize(DEV)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,frames,pad", [("bvh_100_shaded", 4, 0), ("c1_shadows_fresnel", 3, 5), ("fin_dof", 2, 0), ("own_glass_env", 2, 3)])
+def test_deterministic_frames_equal_single_renders(gpu, name, frames, pad):
+    """160x90 fixtures: 90 rows are no multiple of 8, frames follow each other in the launch."""
+    scene_file, params, golden = helpers.load_case(name)
+    scene = rt.Scene(scene_file)
+    one = _single(scene, params, 0)
+    got, rows = _frames(scene, params, frames, slice_rows=rows_plus(scene, params, pad))
+    scene.close()
+    assert helpers.diff_stats(one, golden)[0] <= 1
+    for f in range(frames):
+        mx, nd, _ = helpers.diff_stats(got[f, :rows], one)
+        assert mx <= 1 and nd <= 0.002 * one.size, (f, mx, nd)
+    if pad and name == "bvh_100_shaded":
+        assert (got[:, rows:] == 7).all()
+
+
+def rows_plus(scene, params, pad):
+    return 0 if pad == 0 else rt.part_rows(scene.height, params.tile_rows or 8, params.part_index, max(params.part_count, 1)) + pad
+
+
+@pytest.mark.parametrize("part", [(0, 1), (1, 3), (7, 8)])
+def test_full_hd_parts_with_alternating_bands(gpu, part):
+    """1080 rows and their parts of 8-row tiles are multiples of 8: the bands of the frames alternate in the launch.
+    Direct-output frame (20000 ellipsoids) and the default scene with shadows (queues, bundles, accumulators)."""
+    index, count = part
+    desc = workloads.bvh_stress_scene(20000, 1920, 1080)
+    scene = rt.Scene(desc)
+    params = workloads.default_config().params(rng="d0")
+    params.tile_rows, params.part_index, params.part_count = 8, index, count
+    one = _single(scene, params, 0)
+    got, rows = _frames(scene, params, 5, slice_rows=rt.part_rows(1080, 8, 0, count))
+    scene.close()
+    assert rows % 8 == 0 and one.any()
+    for f in range(5):
+        assert np.array_equal(got[f, :rows], one)
+    scene_file, p2, golden = helpers.load_case("c1_1080p")
+    p2.tile_rows, p2.part_index, p2.part_count = 8, index, count
+    p2.shadows, p2.fresnel = 1, 1
+    scene = rt.Scene(scene_file)
+    one = _single(scene, p2, 0)
+    got, rows = _frames(scene, p2, 3)
+    scene.close()
+    for f in range(3):
+        mx, nd, _ = helpers.diff_stats(got[f], one)
+        assert mx <= 1 and nd <= 0.002 * one.size
+
+
+def test_seeded_frames_use_consecutive_seeds(gpu):
+    """Stochastic sampling: frame f of the batch is the frame rendered alone with seed + f (same samples; sums differ only
+    by the order of the FP64 additions), and differs from frame f + 1."""
+    scene_file, params, _ = helpers.load_case("st_soft_shadows", rng="seeded")
+    params.samples_per_pixel = 4
+    params.seed = 11
+    scene = rt.Scene(scene_file)
+    got, rows = _frames(scene, params, 3)
+    for f in range(3):
+        one = _single(scene, params, f)
+        mx, nd, _ = helpers.diff_stats(got[f], one)
+        assert mx <= 1 and nd <= 0.05 * one.size, (f, mx, nd)
+    assert helpers.diff_stats(got[0], got[1])[1] > 0.05 * got[0].size
+    scene.close()
+
+
+def test_frames_arguments_are_checked(gpu):
+    scene_file, params, _ = helpers.load_case("c1_default")
+    scene = rt.Scene(scene_file)
+    buf = torch.zeros((2, scene.height, scene.width, 3), dtype=torch.uint8, device=DEV)
+    with pytest.raises(rt.RtError):
+        scene.render_frames_device(params, 0, buf.data_ptr())
+    with pytest.raises(rt.RtError):
+        scene.render_frames_device(params, 2, buf.data_ptr(), slice_rows=scene.height - 1)
+    mega = params.copy()
+    mega.schedule = 1
+    with pytest.raises(rt.RtError):
+        scene.render_frames_device(mega, 2, buf.data_ptr())
+    scene.close()
