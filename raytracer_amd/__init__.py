@@ -455,8 +455,13 @@ def bvh_order_device(scene_desc):
     return order[: d.contents.n_shapes], ms.value
 
 
-NODE4_DTYPE = np.dtype([("org", "<f4", 3), ("exps", "<u4"), ("qlo", "<u4", 3), ("qhi", "<u4", 3), ("child", "<i4", 4),
-                        ("pad", "<i4", 2)])   # device_types.h: DNode4 (64 bytes)
+NODE4_DTYPE = np.dtype([("org", "<f4", 3), ("step_x", "<f4"), ("qlo", "<u4", 3), ("qhi", "<u4", 3), ("child", "<i4", 4),
+                        ("step_yz", "<f4", 2)])   # device_types.h: DNode4 (64 bytes)
+
+
+def node4_steps(node):
+    """Grid steps (x, y, z) of one NODE4_DTYPE record: powers of two, stored as FP32 numbers."""
+    return (float(node["step_x"]), float(node["step_yz"][0]), float(node["step_yz"][1]))
 EMPTY_CHILD = 0x7FFFFFFF
 
 

@@ -257,8 +257,6 @@ __global__ void __launch_bounds__(kB) k_lbvh_emit(const int n, const double pad,
         count = c + 1;   // used slots are the first ones
     }
     DNode4 o;
-    o.exps = 0;
-    o.pad[0] = o.pad[1] = 0;
     for (int c = 0; c < 4; ++c) o.child[c] = child[c];
     // host_bvh.cpp: Collapser::quantise, operation by operation
     for (int a = 0; a < 3; ++a) {
@@ -291,7 +289,7 @@ __global__ void __launch_bounds__(kB) k_lbvh_emit(const int n, const double pad,
             whi = (whi & ~(0xffu << (8 * c))) | ((unsigned)qh << (8 * c));
         }
         o.org[a] = org;
-        o.exps |= (unsigned)(e + 127) << (8 * a);
+        (a == 0 ? o.step_x : o.step_yz[a - 1]) = (float)step;
         o.qlo[a] = wlo;
         o.qhi[a] = whi;
     }

@@ -603,8 +603,8 @@ __device__ __forceinline__ bool closest_hit_small(const DScene& S, const DParams
 // One 4-wide node (device_types.h: DNode4) pulled into registers with four 16-byte loads issued back to back.
 typedef unsigned rt_u4 __attribute__((ext_vector_type(4)));
 struct NodeRegs {
-    float org[3];
-    unsigned exps, qlo[3], qhi[3];
+    float org[3], step[3];
+    unsigned qlo[3], qhi[3];
     int child[4];
 };
 __device__ __forceinline__ NodeRegs load_node(const DNode4* n) {
@@ -612,7 +612,7 @@ __device__ __forceinline__ NodeRegs load_node(const DNode4* n) {
     const rt_u4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
     NodeRegs r;
     r.org[0] = __uint_as_float(a0.x); r.org[1] = __uint_as_float(a0.y); r.org[2] = __uint_as_float(a0.z);
-    r.exps = a0.w;
+    r.step[0] = __uint_as_float(a0.w); r.step[1] = __uint_as_float(a3.z); r.step[2] = __uint_as_float(a3.w);
     r.qlo[0] = a1.x; r.qlo[1] = a1.y; r.qlo[2] = a1.z;
     r.qhi[0] = a1.w; r.qhi[1] = a2.x; r.qhi[2] = a2.y;
     r.child[0] = (int)a2.z; r.child[1] = (int)a2.w; r.child[2] = (int)a3.x; r.child[3] = (int)a3.y;
@@ -636,7 +636,7 @@ __device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, flo
     unsigned qn[3], qf[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float ak = __uint_as_float(((n.exps >> (8 * k)) & 0xffu) << 23) * f.inv[k];   // power of two: exact
+        const float ak = n.step[k] * f.inv[k];   // power of two: exact
         const float bk = fmaf(n.org[k], f.inv[k], -f.oi[k]);
         a[k] = rt_f2{ak, ak};
         b[k] = rt_f2{bk, bk};
@@ -660,7 +660,9 @@ __device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, flo
 #endif
         tn = fmaxf(tn, tmin);
         tf = fminf(tf, tmax);
-        e[c] = (tf >= tn && n.child[c] != kEmptyChild) ? tn : INFINITY;
+        // (an unused slot holds an inverted box: planes 255 / 0 on every axis, and the step is never zero, so tf < tn on every
+        // axis the ray is not parallel to -- there is one -- and the slot's reference is never looked at)
+        e[c] = (tf >= tn) ? tn : INFINITY;
     }
 }
 

@@ -39,7 +39,7 @@ struct alignas(128) DNode {
 static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 
 // What the device actually traverses: the binary tree collapsed to four children per node (host_bvh.cpp: to_node4),
-// child boxes quantised to 8 bits per plane on a per-node grid: plane = org[axis] + q * 2^(exp[axis] - 127).  Boxes
+// child boxes quantised to 8 bits per plane on a per-node grid: plane = org[axis] + q * step[axis], step a power of two.  Boxes
 // are moved outward before quantisation (lower planes rounded down, upper planes up), so the FP32 slab test of
 // device_rt.h accepts every ray the reference's FP64 test (aabb.cpp:4-38) accepts on the original boxes.  Boxes only
 // cull; every hit/miss decision is made by the FP64 primitive tests, so a conservative (superset) traversal yields
@@ -47,11 +47,13 @@ static_assert(sizeof(DNode) == 128, "DNode must be 128 bytes");
 constexpr int32_t kEmptyChild = 0x7fffffff;
 struct alignas(64) DNode4 {
     float org[3];        // grid origin (<= every lower plane)
-    uint32_t exps;       // biased FP32 exponent of the grid step per axis: x | y << 8 | z << 16
+    float step_x;        // grid step per axis, a power of two >= 2^-126, stored as the FP32 number itself (step_yz below): the
+                         // node loop multiplies it by 1/d without decoding anything
     uint32_t qlo[3];     // [axis], byte c = lower plane of child c
     uint32_t qhi[3];     // [axis], byte c = upper plane of child c
-    int32_t child[4];    // >= 0 interior node, < 0 leaf (make_leaf_ref), kEmptyChild = unused slot
-    int32_t pad[2];
+    int32_t child[4];    // >= 0 interior node, < 0 leaf (make_leaf_ref), kEmptyChild = unused slot, whose box is INVERTED on every
+                         // axis (lower plane 255, upper plane 0): no ray enters it, so the node loop never looks at the reference
+    float step_yz[2];
 };
 static_assert(sizeof(DNode4) == kNodeBytes, "DNode4 must be 64 bytes");
 

@@ -485,13 +485,11 @@ struct Collapser {
     }
 
     void quantise(DNode4& o, const std::vector<Slot>& slots, const int32_t refs[4]) const {
-        o.exps = 0;
         for (int a = 0; a < 3; ++a) {
             o.qlo[a] = 0xffffffffu;   // unused slots: lower plane above upper plane
             o.qhi[a] = 0u;
         }
         for (int c = 0; c < 4; ++c) o.child[c] = refs[c];
-        o.pad[0] = o.pad[1] = 0;
         for (int a = 0; a < 3; ++a) {
             double lo = std::numeric_limits<double>::infinity(), hi = -lo;
             for (const Slot& s : slots) {
@@ -516,7 +514,7 @@ struct Collapser {
             };
             while (e < 127 && q_of(hi, true, e) > 255.0) ++e;
             o.org[a] = org;
-            o.exps |= static_cast<uint32_t>(e + 127) << (8 * a);
+            (a == 0 ? o.step_x : o.step_yz[a - 1]) = std::ldexp(1.0f, e);   // -126 <= e <= 127: a normal FP32 number, never zero
             uint32_t wlo = o.qlo[a], whi = o.qhi[a];
             for (size_t c = 0; c < slots.size(); ++c) {
                 double ql = q_of(std::max(slots[c].box.lo[a] - pad, static_cast<double>(org)), false, e);

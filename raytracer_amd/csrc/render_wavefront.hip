@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 #define RT_CHUNK 64               // rays a wave reserves from the queue per atomic
 #endif
 #ifndef RT_REFILL_VOTE
-#define RT_REFILL_VOTE 8          // fetch new rays once this many lanes are idle
+#define RT_REFILL_VOTE 16         // fetch new rays once this many lanes are idle (8: 3.5 % slower, 24: 6 % slower on the C2 frame)
 #endif
 
 // The queue is cut into one contiguous share per XCD, each with its own fetch counter (on its own cache line): the

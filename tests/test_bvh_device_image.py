@@ -13,7 +13,8 @@ def _child_boxes(node):
     """[4, 6] dequantised boxes (lo xyz, hi xyz) of one node, in float64 (exact: org is FP32, steps are powers of two)."""
     out = np.zeros((4, 6))
     for a in range(3):
-        step = np.ldexp(1.0, int((int(node["exps"]) >> (8 * a)) & 0xFF) - 127)
+        step = rt.node4_steps(node)[a]
+        assert step > 0.0 and np.frexp(step)[0] == 0.5, "grid steps are powers of two, never zero"
         for c in range(4):
             out[c, a] = float(node["org"][a]) + float((int(node["qlo"][a]) >> (8 * c)) & 0xFF) * step
             out[c, 3 + a] = float(node["org"][a]) + float((int(node["qhi"][a]) >> (8 * c)) & 0xFF) * step
@@ -55,7 +56,7 @@ def _check_image(img, n_prims, check_root_box=True):
             assert np.all(cb[c, 3:6] >= hi + pad), (ref, c, cb[c], hi, pad)
             # and not absurdly loose: within two grid steps + pad of the true box on every axis
             for a in range(3):
-                step = np.ldexp(1.0, int((int(node["exps"]) >> (8 * a)) & 0xFF) - 127)
+                step = rt.node4_steps(node)[a]
                 assert cb[c, a] >= lo[a] - pad - 2 * step and cb[c, 3 + a] <= hi[a] + pad + 2 * step
             lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
         assert used >= 2

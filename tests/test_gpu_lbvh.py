@@ -185,7 +185,7 @@ def test_device_sah_is_the_host_sah_tree(sah_gpu, n, clustered):
             out = []
             for nd in nodes:
                 leaves = tuple(sorted(int(c) for c in nd["child"] if c < 0))
-                out.append((tuple(nd["org"].tolist()), int(nd["exps"]), tuple(sorted(zip(*[[(int(nd["qlo"][a]) >> (8 * c)) & 255 for c in range(4)] for a in range(3)] +
+                out.append((tuple(nd["org"].tolist()), rt.node4_steps(nd), tuple(sorted(zip(*[[(int(nd["qlo"][a]) >> (8 * c)) & 255 for c in range(4)] for a in range(3)] +
                                                                                       [[(int(nd["qhi"][a]) >> (8 * c)) & 255 for c in range(4)] for a in range(3)]))), leaves))
             return sorted(out)
         if n <= 1000:
