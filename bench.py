@@ -5,9 +5,9 @@ Metric (BASELINE.json): Mrays/s (primary + secondary) and ms/frame, 1080p Whitte
 Workload: BASELINE config 2 — 10^6 seeded random ellipsoids (raytracer_amd.workloads.bvh_stress_scene), 1920x1080,
 1 spp, default flags, shipped config values; deterministic sampling (RT_RNG_D0) so that every step traces the same rays.
 
-A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernels, 16 frames per call
+A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernels, 16 frames per GPU of the job per call
 (C-ABI rt_render_frames_device: the rays of the frames share the ray queues and one launch of every kernel; two such
-calls in flight on HIP streams of their own), and the u8 slices of the 16 frames travel to rank 0 inside the library in
+calls in flight on HIP streams of their own), and the u8 slices of those frames travel to rank 0 inside the library in
 one exchange (rt_gather_frames: RCCL send/recv + k_deinterleave).  The scene is resident in HBM when the timed region starts and the
 frame stays in HBM.  value = rays of all ranks / max-over-ranks time.  Scaling is "strong": the frame is fixed as N grows.
 `python bench.py --gpus N` without a launcher's environment starts its N ranks itself (torch.distributed.run) and fails
@@ -64,14 +64,15 @@ VALU_PEAK_FP32_TFLOPS = 157.3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--spheres", type=int, default=1_000_000, help="C2 primitive count (default = the named config)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile-rows", type=int, default=8)
-    ap.add_argument("--frames-per-launch", type=int, default=16,
-                    help="frames rendered per call (rt_render_frames_device) and sent to rank 0 per exchange")
+    ap.add_argument("--frames-per-launch", type=int, default=None,
+                    help="frames rendered per call (rt_render_frames_device) and sent to rank 0 per exchange; default 16 per GPU of the job, "
+                         "at most 64 (a rank's share of a frame shrinks with the job, so the launch keeps its size)")
     ap.add_argument("--launches-in-flight", type=int, default=2, help="sets of --frames-per-launch frames in flight, each on its own HIP stream")
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="the round-1 setting instead: ONE frame per call (rt_render_device), this many in flight on streams of their own")
@@ -232,7 +233,8 @@ def main():
     # and host cost).  S sets alternate, each on a HIP stream of its own (kernels and the exchange of a set are ordered on
     # its stream), so the next B frames render while the previous exchange is in flight; this one thread issues everything in
     # step order on every rank.  --frames-in-flight F selects the round-1 setting instead: one frame per call on F streams.
-    B, S = max(1, args.frames_per_launch), max(1, args.launches_in_flight)
+    B = max(1, args.frames_per_launch) if args.frames_per_launch else min(64, 16 * world)
+    S = max(1, args.launches_in_flight)
     if args.frames_in_flight is not None:
         B, S = 1, max(1, args.frames_in_flight)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
