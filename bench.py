@@ -3,7 +3,8 @@
 
 Metric (BASELINE.json): Mrays/s (primary + secondary) and ms/frame, 1080p Whitted, 1/2/4/8 GPUs.
 Workload: BASELINE config 2 — 10^6 seeded random ellipsoids (raytracer_amd.workloads.bvh_stress_scene), 1920x1080,
-1 spp, default flags, shipped config values; deterministic sampling (RT_RNG_D0) so that every step traces the same rays.
+1 spp, default flags, shipped config values; the reference's sampling (a random position inside the pixel for every ray, seeded
+per frame; --sampling d0 selects the deterministic mode of the parity tests).
 
 A "step" is one whole frame: every rank renders its interleaved row tiles with the HIP kernels, 16 frames per GPU of the job per call
 (C-ABI rt_render_frames_device: the rays of the frames share the ray queues and one launch of every kernel; two such
@@ -70,6 +71,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--sampling", default="seeded", choices=["seeded", "d0"],
+                    help="seeded: the reference's sampling (main.cpp:288-302: a random position inside the pixel for every ray; frame f of a "
+                         "launch uses seed + f); d0: the deterministic mode of the parity tests (pixel centres, all frames equal)")
     ap.add_argument("--frames-per-launch", type=int, default=None,
                     help="frames rendered per call (rt_render_frames_device) and sent to rank 0 per exchange; default 16 per GPU of the job, "
                          "at most 64 (a rank's share of a frame shrinks with the job, so the launch keeps its size)")
@@ -220,7 +224,7 @@ def main():
 
     cfg = workloads.default_config()
     scene_desc = workloads.bvh_stress_scene(args.spheres, args.width, args.height)
-    params = cfg.params(rng="d0")
+    params = cfg.params(rng=args.sampling, seed=12345)
     params.tile_rows, params.part_index, params.part_count = args.tile_rows, rank, world
     t_create = time.perf_counter()
     scene = rt.Scene(scene_desc)  # BVH build + upload: outside the timed region (scene resident in HBM)
@@ -242,10 +246,18 @@ def main():
     sets = [FrameGather(W, H, args.tile_rows, dev, frames=B) for _ in range(S)]   # slices [B, max_rows, W, 3]; frames on rank 0
     batch_events = []
 
+    # All exchanges are issued on ONE stream of their own, in batch order (operations of a communicator stay ordered whatever
+    # the RCCL version makes of several user streams), tied to the render streams by events both ways: the exchange of a set
+    # waits for the set's render, and the next render into the set waits until its previous exchange has read the slices.
+    gather_stream = torch.cuda.Stream(dev) if world > 1 else None
+    done = [None] * S
+
     def launch(k, nb=None, collect=False, timed=False):
         """Batch k: nb (default B) frames into set k % S and the set's exchange.  Collective: every rank issues the same batches."""
         stream, fg = streams[k % S], sets[k % S]
         with torch.cuda.stream(stream):
+            if done[k % S] is not None:
+                stream.wait_event(done[k % S])
             if timed:
                 batch_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nb or B))
                 batch_events[-1][0].record(stream)
@@ -256,7 +268,15 @@ def main():
                 scene.render_frames_device(params, nb or B, fg.slices.data_ptr(), slice_rows=fg.max_rows, stream=stream.cuda_stream)
             if timed:
                 batch_events[-1][1].record(stream)
-            fg.run()   # RCCL send/recv of the set's slices to rank 0 + k_deinterleave (one GPU: the slices are the frames)
+            if world > 1:
+                rendered = torch.cuda.Event()
+                rendered.record(stream)
+        if world > 1:
+            with torch.cuda.stream(gather_stream):
+                gather_stream.wait_event(rendered)
+                fg.run()   # RCCL send/recv of the set's slices to rank 0 + k_deinterleave
+                done[k % S] = torch.cuda.Event()
+                done[k % S].record(gather_stream)
 
     def run(frames, timed=False, first_batch=0):
         i, k = 0, first_batch
@@ -326,9 +346,12 @@ def main():
             whole = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
             p1 = params.copy()
             p1.part_count, p1.part_index = 1, 0
-            scene.render_device(p1, whole.data_ptr(), stream=streams[0].cuda_stream)
-            torch.cuda.synchronize(dev)
-            frame_ok = all(bool(torch.equal(whole, sets[0].frames[b])) for b in range(B))
+            frame_ok = True
+            for b in range(B):   # frame b of a launch is the frame rendered alone with seed + b
+                p1.seed = params.seed + (b if B > 1 else 0)
+                scene.render_device(p1, whole.data_ptr(), stream=streams[0].cuda_stream)
+                torch.cuda.synchronize(dev)
+                frame_ok = frame_ok and bool(torch.equal(whole, sets[0].frames[b]))
         dist.barrier()
 
     # one frame at a time (latency setting) and the boundary's own contract -- rt_render into a HOST buffer (main.cpp:242,320)
@@ -414,7 +437,7 @@ def main():
                                     % (args.tile_rows, world, "rt_gather_frames: RCCL send/recv + k_deinterleave" if args.backend == "nccl" else args.backend + " REHEARSAL, not a measurement"),
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
-                       "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "deterministic (RT_RNG_D0)",
+                       "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "seeded: a random position inside the pixel per ray as in main.cpp:288-302, frame f of a launch with seed + f" if args.sampling == "seeded" else "deterministic (RT_RNG_D0: pixel centres)",
                        "frames_per_launch": B, "launches_in_flight": S, "frames_in_flight": B * S,
                        "frames_per_exchange": B if world > 1 else None, "scene_create_ms": round(t_create * 1e3, 1),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rays_per_lane": os.environ.get("RT_RAYS_PER_LANE"),

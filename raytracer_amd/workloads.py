@@ -96,10 +96,10 @@ def write_pfm_float32(path, img):
 _REPO = os.path.dirname(_HERE)
 GOLDEN_DIR = os.path.join(_REPO, "tests", "golden")
 BASELINE_CONFIGS = [   # label, fixture, width, height, samples per pixel, sampling
-    ("C1: ASCII/scene.txt, Whitted 1 spp", "c1_default", 1920, 1080, 1, "d0"),
-    ("C1 + --shadows --fresnel", "c1_shadows_fresnel", 1920, 1080, 1, "d0"),
+    ("C1: ASCII/scene.txt, Whitted 1 spp", "c1_default", 1920, 1080, 1, "seeded"),
+    ("C1 + --shadows --fresnel", "c1_shadows_fresnel", 1920, 1080, 1, "seeded"),
     ("C3: dof.txt, soft shadows + glossy + depth of field, 64 spp", "st_dof", 1920, 1080, 64, "seeded"),
-    ("C4: displaced + textured + bump-mapped shapes, metal + glass, 4096x2048 HDR environment, ACES", "c4_combined", 1920, 1080, 1, "d0"),
+    ("C4: displaced + textured + bump-mapped shapes, metal + glass, 4096x2048 HDR environment, ACES", "c4_combined", 1920, 1080, 1, "seeded"),
     ("C5 share: motion_blur.txt, 3840x2160, 16 of the 1024 spp (cost is linear in spp)", "st_motion_blur", 3840, 2160, 16, "seeded"),
 ]
 
