@@ -186,10 +186,24 @@ def other_configs(dev):
                     e1.record(stream)
                 torch.cuda.synchronize(dev)
                 ms = e0.elapsed_time(e1) / reps
+                ms16 = None
+                if spp == 1:   # a 1-spp frame is a handful of small launches: 16 frames (seeds seed + f) per call share them
+                    buf16 = torch.empty((16, h, w, 3), dtype=torch.uint8, device=dev)
+                    sc.render_frames_device(p, 16, buf16.data_ptr(), stream=stream.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    with torch.cuda.stream(stream):
+                        e0.record(stream)
+                        for _ in range(2):
+                            sc.render_frames_device(p, 16, buf16.data_ptr(), stream=stream.cuda_stream)
+                        e1.record(stream)
+                    torch.cuda.synchronize(dev)
+                    ms16 = e0.elapsed_time(e1) / 32
+                    del buf16
                 sc.close()
                 k = shares.get(name, {})
                 res.append({"config": label, "fixture": name, "resolution": [w, h], "spp": spp, "rays_per_frame": int(st.rays),
                             "ms": round(ms, 3), "Mrays_per_s": round(st.rays / ms / 1e3, 1), "frames_timed": reps,
+                            "ms_per_frame_16_frames_per_call": round(ms16, 3) if ms16 else None, "sampling": rng,
                             "dominant_kernel": k.get("kernel"), "dominant_kernel_fraction": k.get("fraction"),
                             "dominant_kernel_source": k.get("source")})
             except Exception as e:   # the headline does not depend on these

@@ -306,7 +306,7 @@ class Config:
         return apply_flags(p, self, **flags)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # (lib is None while the interpreter shuts down)
             lib.rt_config_destroy(self._h)
             self._h = None
 
@@ -369,7 +369,7 @@ class SceneFile:
         return self.desc.camera.resolution_y
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.rt_scene_file_destroy(self._h)
             self._h = None
 
@@ -562,7 +562,7 @@ class Scene:
         return ms.value, n.value
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.rt_scene_destroy(self._h)
             self._h = None
 
