@@ -112,3 +112,20 @@ def test_frames_arguments_are_checked(gpu):
     with pytest.raises(rt.RtError):
         scene.render_frames_device(mega, 2, buf.data_ptr())
     scene.close()
+
+
+@pytest.mark.parametrize("name", ["c1_shadows_fresnel", "bvh_100_shaded"])
+def test_frames_cut_into_chunks(gpu, monkeypatch, name):
+    """RT_QUEUE_RAYS at its minimum: the rows of the launch (frames follow each other: 90 rows) are generated in many chunks of
+    8-row bands that straddle frames, every level is cut into batches; the slices still hold the single frames."""
+    scene_file, params, golden = helpers.load_case(name)
+    scene = rt.Scene(scene_file)
+    one = _single(scene, params, 0)
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    got, rows = _frames(scene, params, 3)
+    monkeypatch.delenv("RT_QUEUE_RAYS")
+    scene.close()
+    rt.release_workspaces()
+    for f in range(3):
+        mx, nd, _ = helpers.diff_stats(got[f], one)
+        assert mx <= 1 and nd <= 0.002 * one.size, (f, mx, nd)
