@@ -77,7 +77,8 @@ def parse_args():
     ap.add_argument("--frames-per-launch", type=int, default=None,
                     help="frames rendered per call (rt_render_frames_device) and sent to rank 0 per exchange; default 16 per GPU of the job, "
                          "at most 64 (a rank's share of a frame shrinks with the job, so the launch keeps its size)")
-    ap.add_argument("--launches-in-flight", type=int, default=2, help="sets of --frames-per-launch frames in flight, each on its own HIP stream")
+    ap.add_argument("--sets", type=int, default=2, help="slice buffers that alternate, so that the exchange of one launch's frames overlaps the next launch "
+                                                         "(all launches are issued on ONE stream: two traversal launches side by side were measured slower)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="the round-1 setting instead: ONE frame per call (rt_render_device), this many in flight on streams of their own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,14 +249,16 @@ def main():
     # ends with a tail of its longest rays, so B frames are rendered per call (rt_render_frames_device: the rays of the B
     # frames share the queues and one tail) into the B slices of a set, and the set travels to rank 0 in ONE exchange
     # (rt_gather_frames: at 8 ranks a rank's share of a frame is 0.78 MB, so a message per frame would be bound by its launch
-    # and host cost).  S sets alternate, each on a HIP stream of its own (kernels and the exchange of a set are ordered on
-    # its stream), so the next B frames render while the previous exchange is in flight; this one thread issues everything in
-    # step order on every rank.  --frames-in-flight F selects the round-1 setting instead: one frame per call on F streams.
+    # and host cost).  All launches go to one HIP stream, back to back (the call is asynchronous for this frame: nothing is
+    # read back); S sets of slices alternate, so that the exchange of one launch's frames, on a stream of its own, overlaps
+    # the next launch.  This one thread issues everything in step order on every rank.
+    # --frames-in-flight F selects the round-1 setting instead: one frame per call on F streams.
     B = max(1, args.frames_per_launch) if args.frames_per_launch else min(64, 16 * world)
-    S = max(1, args.launches_in_flight)
+    S, n_streams = max(1, args.sets), 1
     if args.frames_in_flight is not None:
         B, S = 1, max(1, args.frames_in_flight)
-    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+        n_streams = S
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)   # RT_N_COUNTERS
     sets = [FrameGather(W, H, args.tile_rows, dev, frames=B) for _ in range(S)]   # slices [B, max_rows, W, 3]; frames on rank 0
     batch_events = []
@@ -268,7 +271,7 @@ def main():
 
     def launch(k, nb=None, collect=False, timed=False):
         """Batch k: nb (default B) frames into set k % S and the set's exchange.  Collective: every rank issues the same batches."""
-        stream, fg = streams[k % S], sets[k % S]
+        stream, fg = streams[k % n_streams], sets[k % S]
         with torch.cuda.stream(stream):
             if done[k % S] is not None:
                 stream.wait_event(done[k % S])
@@ -343,7 +346,7 @@ def main():
     traverse_ms_in_flight = sum(ms for ms, _ in tt) / max(1, launches)
     # roofline pass: the same batches one at a time on one stream (no barrier needed: ranks render independently), so that a
     # launch's duration is the kernel's own; this is what `rocprofv3 --kernel-trace --stats -- python3 bench.py
-    # --launches-in-flight 1` reports too
+    # ` reports too
     for i in range(3 if B > 1 else max(3, min(args.steps, 10))):
         launch(0)
         torch.cuda.synchronize(dev)
@@ -452,7 +455,7 @@ def main():
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "seeded: a random position inside the pixel per ray as in main.cpp:288-302, frame f of a launch with seed + f" if args.sampling == "seeded" else "deterministic (RT_RNG_D0: pixel centres)",
-                       "frames_per_launch": B, "launches_in_flight": S, "frames_in_flight": B * S,
+                       "frames_per_launch": B, "slice_sets": S, "render_streams": n_streams,
                        "frames_per_exchange": B if world > 1 else None, "scene_create_ms": round(t_create * 1e3, 1),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rays_per_lane": os.environ.get("RT_RAYS_PER_LANE"),
                        "gathered_frame_equals_whole_frame": frame_ok},

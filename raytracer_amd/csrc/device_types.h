@@ -15,7 +15,10 @@
 namespace rt {
 
 constexpr int kNodeBytes = 64;        // one DNode4 (what the device traverses)
-constexpr int kTravLdsEntries = 16;   // per-lane traversal stack entries kept in LDS (8 bytes each)
+#ifndef RT_TRAV_LDS_ENTRIES
+#define RT_TRAV_LDS_ENTRIES 14
+#endif
+constexpr int kTravLdsEntries = RT_TRAV_LDS_ENTRIES;   // per-lane traversal stack entries kept in LDS (8 bytes each)
 constexpr int kTravSpillEntries = 80; // further entries in per-lane scratch memory (deep, unbalanced hierarchies only)
 constexpr int kTravStackDepth = kTravLdsEntries + kTravSpillEntries;
 constexpr int kMaxBinaryDepth = 31;   // interior levels of the binary tree; a 4-wide node defers <= 3 children per level
