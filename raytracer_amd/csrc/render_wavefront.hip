@@ -865,8 +865,9 @@ __global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S
 // ordinary shadow ray of the next level's queue (shade_ray continues it there).
 constexpr int kInlineSegments = 6;
 #ifndef RT_SHADOW_WAVES
-#define RT_SHADOW_WAVES 3         // waves per SIMD asked of the register allocator: 3 measured 5-8 % faster than 2 on the analytic
-#endif                            // variants; the variant with the ray marcher and the texture paths spills at that budget (x 1.6)
+#define RT_SHADOW_WAVES 4         // waves per SIMD asked of the register allocator: 3 measured 5-8 % faster than 2 on the analytic
+#endif                            // variants and 4 another 2-3.5 % on the 64-spp frames (5: spills, x 1.2 - 1.4 slower); the variant with
+                                  // the ray marcher and the texture paths spills already at 3 (x 1.6) and stays at 2
 template <int F, bool SMALL>
 __global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? 2 : RT_SHADOW_WAVES)
 k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn in, const EmitCtx E0, double* __restrict__ accum,
