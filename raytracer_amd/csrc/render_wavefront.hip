@@ -810,7 +810,10 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 #define RT_SHADE_WAVES 1          // waves per SIMD asked of the register allocator for the shading kernel
 #endif
 template <int F, bool EMIT, bool SMALL>
-__global__ void __launch_bounds__(kBlock, RT_SHADE_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
+#ifndef RT_SHADE_LEAN_WAVES
+#define RT_SHADE_LEAN_WAVES 4     // ... for the variant that cannot queue a ray (no emission code: 136 registers without a bound)
+#endif
+__global__ void __launch_bounds__(kBlock, EMIT ? RT_SHADE_WAVES : ((F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_WAVES : RT_SHADE_LEAN_WAVES)) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
                                                   const HitQ hits_all, const QIn in, const EmitCtx E, double* __restrict__ accum) {
     __shared__ SceneStage<SMALL> staged;
     const BlockSpan span = block_span(in);
