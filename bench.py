@@ -207,6 +207,8 @@ def other_configs(dev):
                             "ms_per_frame_16_frames_per_call": round(ms16, 3) if ms16 else None, "sampling": rng,
                             "dominant_kernel": k.get("kernel"), "dominant_kernel_fraction": k.get("fraction"),
                             "dominant_kernel_source": k.get("source")})
+                if k.get("valu"):   # VALU issue and lane fractions of the frame's kernels, from the committed PMC passes
+                    res[-1]["valu"] = k["valu"]
             except Exception as e:   # the headline does not depend on these
                 res.append({"config": label, "fixture": name, "error": str(e)[:200]})
         rt.release_workspaces()

@@ -88,9 +88,23 @@ for f in sorted(glob.glob(os.path.join(src, "cfg_*_kernel_stats.csv"))):
     j = os.path.join(src, "cfg_%s.json" % name)
     if os.path.exists(j):
         shutil.copy(j, "%s/%s_cfg_%s.json" % (dst, rnd, name))
+c3 = pmc("c3pmc")
+if c3 and "st_dof" in cfg:
+    # VALU position of the shading-heavy frame (small scenes): totals over one PMC run = 6 frames at 8 spp
+    tot_i = sum(sum(v["SQ_INSTS_VALU"]) for v in c3.values() if "SQ_INSTS_VALU" in v)
+    tot_l = sum(sum(v["SQ_THREAD_CYCLES_VALU"]) for v in c3.values() if "SQ_THREAD_CYCLES_VALU" in v)
+    gui = sum(sum(v["GRBM_GUI_ACTIVE"]) for v in c3.values() if "GRBM_GUI_ACTIVE" in v) / 8.0 / 2.4e9   # summed over the 8 XCDs
+    per = {}
+    for k, v in c3.items():
+        if "SQ_INSTS_VALU" in v and sum(v["SQ_INSTS_VALU"]) > 0.01 * tot_i:
+            i = sum(v["SQ_INSTS_VALU"])
+            per[k] = {"wave_instructions": int(i), "active_lane_fraction": round(sum(v["SQ_THREAD_CYCLES_VALU"]) / 64.0 / i, 3),
+                      "issue_ms": round(i * 4 / (1024 * 2.4e9) * 1e3, 2), "busy_ms": round(sum(v["GRBM_GUI_ACTIVE"]) / 8.0 / 2.4e9 * 1e3, 2)}
+    cfg["st_dof"]["valu"] = {"run": "6 frames at 8 spp (scratch/bench_configs.py st_dof, RT_BENCH_SPP=8), separate rocprofv3 --pmc passes",
+                             "issue_fraction": round(tot_i * 4 / (1024 * 2.4e9) / gui, 3), "active_lane_fraction": round(tot_l / 64.0 / tot_i, 3),
+                             "kernels": per, "source": "profiles/%s_c3_pmc_summary.txt" % rnd}
 json.dump(cfg, open(dst + "/config_kernels.json", "w"), indent=1)
 print(json.dumps(cfg, indent=1))
-c3 = pmc("c3pmc")
 with open("%s/%s_c3_pmc_summary.txt" % (dst, rnd), "w") as o:
     o.write("# rocprofv3 --pmc, one pass per run, scratch/bench_configs.py st_dof at 8 spp (6 frames per run), build %s: totals over the run\n" % build)
     for k in c3:
