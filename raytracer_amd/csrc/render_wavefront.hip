@@ -809,10 +809,13 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 1          // waves per SIMD asked of the register allocator for the shading kernel
 #endif
-template <int F, bool EMIT, bool SMALL>
 #ifndef RT_SHADE_LEAN_WAVES
 #define RT_SHADE_LEAN_WAVES 4     // ... for the variant that cannot queue a ray (no emission code: 136 registers without a bound)
 #endif
+// (Tracing the rays of a small scene inside this kernel instead of in k_traverse_small -- no hit records, one launch per
+// level less -- was built and measured: the kernel grows from 223 to 255 registers and C3 at 16 spp takes 47.6 instead of
+// 40.3 ms, C1 0.67 instead of 0.66 ms: the traversal loop runs better at its own 4 waves per SIMD than inside this kernel's 2.)
+template <int F, bool EMIT, bool SMALL>
 __global__ void __launch_bounds__(kBlock, EMIT ? RT_SHADE_WAVES : ((F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_WAVES : RT_SHADE_LEAN_WAVES)) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
                                                   const HitQ hits_all, const QIn in, const EmitCtx E, double* __restrict__ accum) {
     __shared__ SceneStage<SMALL> staged;
