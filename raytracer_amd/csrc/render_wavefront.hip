@@ -1559,6 +1559,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     // persistent traversal grid: as many workgroups per CU as the variant's registers and LDS stacks (30 KB per 256-thread block) allow
     D.traverse_blocks = ws.compute_units * (D.variant == 0 ? RT_TRAVERSE_WAVES_SPHERES : RT_TRAVERSE_WAVES);
     if (const char* tb = getenv("RT_TRAVERSE_BLOCKS_PER_CU")) D.traverse_blocks = ws.compute_units * std::max(1, atoi(tb));
+    // RT_TRAVERSE_SPARE_BLOCKS: workgroups left out of the persistent grid, so that kernels of other streams -- the RCCL
+    // send / receive kernels of an exchange that overlaps the render -- find a free slot before the launch has drained
+    if (const char* sb = getenv("RT_TRAVERSE_SPARE_BLOCKS")) D.traverse_blocks = std::max(ws.compute_units, D.traverse_blocks - std::max(0, atoi(sb)));
 
     // Primary rays are generated in chunks of whole 8-row bands x a batch of samples, sized so that the first
     // level's children always fit one queue.
