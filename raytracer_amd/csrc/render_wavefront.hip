@@ -874,8 +874,11 @@ constexpr int kInlineSegments = 6;
 #define RT_SHADOW_WAVES 4         // waves per SIMD asked of the register allocator: 3 measured 5-8 % faster than 2 on the analytic
 #endif                            // variants and 4 another 2-3.5 % on the 64-spp frames (5: spills, x 1.2 - 1.4 slower); the variant with
                                   // the ray marcher and the texture paths spills already at 3 (x 1.6) and stays at 2
+#ifndef RT_SHADOW_TEX_WAVES
+#define RT_SHADOW_TEX_WAVES 2     // ... of the analytic + textures variant
+#endif
 template <int F, bool SMALL>
-__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? 2 : RT_SHADOW_WAVES)
+__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_ENV)) ? 2 : (F & RT_FEAT_TEXTURE) ? RT_SHADOW_TEX_WAVES : RT_SHADOW_WAVES)
 k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn in, const EmitCtx E0, double* __restrict__ accum,
          unsigned long long* __restrict__ stats) {
     __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
@@ -1108,6 +1111,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve_sum(const double* __restrict
 constexpr int kSpheres = RT_FEAT_SPHERE;
 constexpr int kAnalytic = RT_FEAT_SPHERE | RT_FEAT_QUAD | RT_FEAT_CUBE;
 constexpr int kFull = kAnalytic | RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV;
+constexpr int kTextured = kAnalytic | RT_FEAT_TEXTURE;   // k_shadow only: analytic shapes whose transmitting occluders may carry bump maps
 
 constexpr size_t kMaxTimedEvents = 8192;   // start/stop events kept per workspace until they are collected
 constexpr size_t kMinQueueRays = size_t(1) << 16;
@@ -1120,6 +1124,10 @@ struct Driver {
     WavefrontWorkspace& ws;
     hipStream_t stream;
     int variant;
+    // Traversal only looks at geometry (textures are sampled by the ray marcher of the displaced shapes alone), and the shadow
+    // kernel at geometry plus the bump maps of transmitting occluders: a textured scene without displaced shapes is traversed by
+    // the analytic variants, which need half the registers of the full one.
+    int trav_variant = 2, shadow_variant = 2;   // 0 spheres, 1 analytic, 2 full, 3 (shadow) analytic + textures
     int traverse_blocks;
     unsigned long long rays_traced = 0;
     bool may_emit = true;   // false: no launch of k_shade can queue a ray
@@ -1239,8 +1247,9 @@ struct Driver {
     }
     void shadow(unsigned n, int qo, int out_level) {
         if (!with_shadows()) return;
-        if (variant == 0) launch_shadow<kSpheres>(n, qo, out_level);
-        else if (variant == 1) launch_shadow<kAnalytic>(n, qo, out_level);
+        if (shadow_variant == 0) launch_shadow<kSpheres>(n, qo, out_level);
+        else if (shadow_variant == 1) launch_shadow<kAnalytic>(n, qo, out_level);
+        else if (shadow_variant == 3) launch_shadow<kTextured>(n, qo, out_level);
         else launch_shadow<kFull>(n, qo, out_level);
     }
     template <int F> void launch_shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
@@ -1258,8 +1267,8 @@ struct Driver {
             hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
     }
     void traverse(int q, const QIn& in, unsigned bound, int level) {
-        if (variant == 0) launch_traverse<kSpheres>(q, in, bound, level);
-        else if (variant == 1) launch_traverse<kAnalytic>(q, in, bound, level);
+        if (trav_variant == 0) launch_traverse<kSpheres>(q, in, bound, level);
+        else if (trav_variant == 1) launch_traverse<kAnalytic>(q, in, bound, level);
         else launch_traverse<kFull>(q, in, bound, level);
     }
     void shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
@@ -1556,8 +1565,11 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
     D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
+    D.trav_variant = (f & RT_FEAT_COMPLEX) ? 2 : (f & (RT_FEAT_QUAD | RT_FEAT_CUBE)) ? 1 : 0;
+    D.shadow_variant = (f & RT_FEAT_COMPLEX) ? 2 : ((f & RT_FEAT_TEXTURE) && scene.transparent_materials != 0) ? 3 : D.trav_variant;
+    if (getenv("RT_NO_GEOMETRY_VARIANTS")) D.trav_variant = D.shadow_variant = D.variant;   // (A/B runs)
     // persistent traversal grid: as many workgroups per CU as the variant's registers and LDS stacks (30 KB per 256-thread block) allow
-    D.traverse_blocks = ws.compute_units * (D.variant == 0 ? RT_TRAVERSE_WAVES_SPHERES : RT_TRAVERSE_WAVES);
+    D.traverse_blocks = ws.compute_units * (D.trav_variant == 0 ? RT_TRAVERSE_WAVES_SPHERES : RT_TRAVERSE_WAVES);
     if (const char* tb = getenv("RT_TRAVERSE_BLOCKS_PER_CU")) D.traverse_blocks = ws.compute_units * std::max(1, atoi(tb));
     // RT_TRAVERSE_SPARE_BLOCKS: workgroups left out of the persistent grid, so that kernels of other streams -- the RCCL
     // send / receive kernels of an exchange that overlaps the render -- find a free slot before the launch has drained

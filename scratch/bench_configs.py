@@ -15,6 +15,8 @@ CASES = [  # label, golden case, width, height, spp, rng
     ("C4-like: displaced shapes only", "own_complex", 1920, 1080, 1, "d0"),
     ("C4-like: glass + HDR environment", "own_glass_env", 1920, 1080, 1, "d0"),
     ("C5-like: motion blur + area lights, 4K 16 spp", "st_motion_blur", 3840, 2160, 16, "seeded"),
+    ("gallery: 3900 quads", "gal_shapes", 1920, 1080, 1, "seeded"),
+    ("gallery: 2647 quads", "gal_bike", 1920, 1080, 1, "seeded"),
 ]
 
 import tempfile
