@@ -382,6 +382,26 @@ struct TravStack {
             if (count >= 1) push(sp, r1, t1);
         }
     }
+    // pop() for a lane with a parking slot `pend` (0 = free): a popped leaf goes to the free slot and the lane pops on, so
+    // that it comes back with node work if it has any (k_traverse).
+    __device__ __forceinline__ int pop_parking(int& sp, float tmax, int& pend) {
+        while (sp > 0) {
+            --sp;
+            unsigned long long v;
+            if (__builtin_expect(sp < kTravLdsEntries, 1)) {
+                v = lds[sp * stride];
+            } else {
+                v = spill[sp - kTravLdsEntries];
+                asm volatile("" : "+v"(v));
+            }
+            if (__uint_as_float((unsigned)(v >> 32)) <= tmax) {
+                const int ref = (int)(unsigned)v;
+                if (ref < 0 && pend == 0) { pend = ref; continue; }
+                return ref;
+            }
+        }
+        return 0x7fffffff;
+    }
     // Next deferred child whose box the ray enters before tmax (the closest hit so far), or kDoneRef.
     __device__ __forceinline__ int pop(int& sp, float tmax) {
         while (sp > 0) {
@@ -682,6 +702,27 @@ __device__ __forceinline__ int node4_step(const NodeRegs& n, const RayF& f, floa
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
     if (e[0] == INFINITY) return stack.pop(sp, tmax);
+    const int deferred = (e[1] != INFINITY) + (e[2] != INFINITY) + (e[3] != INFINITY);
+    stack.push_sorted(sp, deferred, c[1], e[1], c[2], e[2], c[3], e[3]);
+    return c[0];
+}
+// node4_step for callers that pop themselves (k_traverse: ONE pop loop per step, shared by the lanes whose node had no child
+// for them and the lanes that have just parked a leaf): returns kNoChild instead of popping.
+constexpr int kNoChild = 0x7ffffffe;
+__device__ __forceinline__ int node4_step_nopop(const NodeRegs& n, const RayF& f, float tmin, float tmax, TravStack& stack, int& sp) {
+    float e[4];
+    node4_test(n, f, tmin, tmax, e);
+    int c[4] = {n.child[0], n.child[1], n.child[2], n.child[3]};
+#define RT_CSWAP(i, j)                                                      \
+    {                                                                       \
+        const bool sw = e[j] < e[i];                                        \
+        const float te = sw ? e[j] : e[i], tf_ = sw ? e[i] : e[j];          \
+        const int tc = sw ? c[j] : c[i], td = sw ? c[i] : c[j];             \
+        e[i] = te; e[j] = tf_; c[i] = tc; c[j] = td;                        \
+    }
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+    if (e[0] == INFINITY) return kNoChild;
     const int deferred = (e[1] != INFINITY) + (e[2] != INFINITY) + (e[3] != INFINITY);
     stack.push_sorted(sp, deferred, c[1], e[1], c[2], e[2], c[3], e[3]);
     return c[0];

@@ -498,11 +498,12 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 if (is_node) {
                     const NodeRegs nd = load_node(&S.nodes[cur]);
                     if (COUNT) { C.nodes += node4_children(nd); C.visits++; ray_visits++; }
-                    cur = node4_step(nd, rf, tmin32, tmax32, stack, sp);
-                    if (cur < 0 && pend == 0) {
-                        pend = cur;
-                        cur = stack.pop(sp, tmax32);
-                    }
+                    cur = node4_step_nopop(nd, rf, tmin32, tmax32, stack, sp);
+                    // one pop loop per step for both kinds of lanes that need their next deferred node: no child entered, or
+                    // the nearest child is a leaf, which is parked
+                    bool need = cur == kNoChild;
+                    if (cur < 0 && pend == 0) { pend = cur; need = true; }
+                    if (need) cur = stack.pop_parking(sp, tmax32, pend);
                 }
                 is_node = static_cast<unsigned>(cur) < static_cast<unsigned>(kDone);
                 nn = __popcll(__ballot(is_node));

@@ -1,0 +1,20 @@
+"""scratch/lane_stats.py (with a library built with -DRT_LANE_STATS, RT_MI355X_LIB): lanes of the node steps of k_traverse by state."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracer_amd as rt
+from raytracer_amd import workloads
+rt.init(0)
+dev = torch.device("cuda", 0)
+for w, h in ((1920, 1080), (7680, 4320)):
+    scene = rt.Scene(workloads.bvh_stress_scene(1_000_000, w, h))
+    p = workloads.default_config().params(rng="seeded", seed=1)
+    buf = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    c = torch.zeros(8, dtype=torch.int64, device=dev)
+    scene.render_device(p, buf.data_ptr(), c.data_ptr(), collect_counters=True)
+    torch.cuda.synchronize()
+    v = c.cpu().numpy()
+    steps = max(1, int(v[7]))
+    print("%dx%d: rays %d, node steps of a wave %d (%.2f per ray x 64), idle lanes per step %.1f, lanes holding only leaves %.1f, lanes at a node %.1f; nodes fetched per ray %.1f"
+          % (w, h, v[0], steps, steps * 64.0 / v[0], v[5] / steps, v[6] / steps, 64 - (v[5] + v[6]) / steps, v[4] / v[0]))
+    scene.close()
