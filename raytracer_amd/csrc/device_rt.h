@@ -468,9 +468,15 @@ __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, con
             double sq = sqrt(disc);
             double root = (-b - sq) / (2.0 * a);
             hit = true;
-            if (root < tmin || root > tmax) {
+            // sphere.cpp:60-66 tries the far root when the near one lies outside [tmin, tmax].  The far root is never smaller than
+            // the near one, in floating point too (sq >= 0, and rounding and the division by the same 2a > 0 are monotone), so a
+            // near root beyond tmax -- a sphere behind the closest hit so far, the usual miss -- settles it without the second
+            // division; only a near root before tmin needs the far one.
+            if (root < tmin) {
                 root = (-b + sq) / (2.0 * a);
                 if (root < tmin || root > tmax) hit = false;
+            } else if (root > tmax) {
+                hit = false;
             }
             t = root;
         }
