@@ -495,6 +495,16 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
         if (nn != 0 && nl < RT_LEAF_VOTE && (nn >= RT_NODE_VOTE || nn >= nl)) {
             // ---- interior nodes; while most of the wave still wants one, stay here (no scheduling work per step)
             do {
+#ifdef RT_LANE_STATS
+                if (COUNT) {   // experiment build (scratch/lane_stats.py): lanes of a node step by state -> counters 5 (idle), 6 (no node work), 7 (steps)
+                    const unsigned long long b_idle = __ballot(my == kNone), b_leaf = __ballot(my != kNone && !is_node);
+                    if (lane == 0) {
+                        atomicAdd(&counters[5], (unsigned long long)__popcll(b_idle));
+                        atomicAdd(&counters[6], (unsigned long long)__popcll(b_leaf));
+                        atomicAdd(&counters[7], 1ull);
+                    }
+                }
+#endif
                 if (is_node) {
                     const NodeRegs nd = load_node(&S.nodes[cur]);
                     if (COUNT) { C.nodes += node4_children(nd); C.visits++; ray_visits++; }
@@ -542,8 +552,10 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
             max_visits = max(max_visits, (unsigned)__shfl_down(max_visits, off));
         }
         if (lane == 0) {
+#ifndef RT_LANE_STATS
             atomicMax(&counters[5], (unsigned long long)max_visits);
             atomicMax(&counters[6], (unsigned long long)iters);
+#endif
             atomicAdd(&counters[4], (unsigned long long)visits);
             atomicAdd(&counters[1], (unsigned long long)nodes);
             atomicAdd(&counters[2], (unsigned long long)prims);

@@ -1,4 +1,5 @@
-"""scratch/lane_stats.py (with a library built with -DRT_LANE_STATS, RT_MI355X_LIB): lanes of the node steps of k_traverse by state."""
+"""scratch/lane_stats.py: lanes of the node steps of k_traverse by state.  Needs a library built with the instrumentation:
+scratch/variant.sh lanes -DRT_LANE_STATS, then RT_MI355X_LIB=raytracer_amd/librt_mi355x_lanes.so python scratch/lane_stats.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +15,8 @@ for w, h in ((1920, 1080), (7680, 4320)):
     scene.render_device(p, buf.data_ptr(), c.data_ptr(), collect_counters=True)
     torch.cuda.synchronize()
     v = c.cpu().numpy()
-    steps = max(1, int(v[7]))
-    print("%dx%d: rays %d, node steps of a wave %d (%.2f per ray x 64), idle lanes per step %.1f, lanes holding only leaves %.1f, lanes at a node %.1f; nodes fetched per ray %.1f"
-          % (w, h, v[0], steps, steps * 64.0 / v[0], v[5] / steps, v[6] / steps, 64 - (v[5] + v[6]) / steps, v[4] / v[0]))
+    rays = w * h                       # one ray per pixel; the library adds its word 7 (here: the steps) to the ray counter
+    steps = max(1, int(v[0]) - rays)
+    print("%dx%d: rays %d, node steps of a wave %d, idle lanes per step %.1f, lanes without node work %.1f, lanes at a node %.1f of 64"
+          % (w, h, rays, steps, v[5] / steps, v[6] / steps, 64 - (v[5] + v[6]) / steps))
     scene.close()
