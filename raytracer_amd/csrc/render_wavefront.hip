@@ -46,13 +46,20 @@ constexpr int kKindRadiance = 0, kKindShadow = 1;
 struct alignas(16) RayRec {
     double o[3], d[3], w[3];   // origin, direction, colour weight of whatever this ray returns
     double time;
-    double tmax;               // radiance: 1e5 (tracer.h:156); shadow: distance to the light sample (shading.h:45)
-    unsigned long long rng;    // state of this ray's random stream
+    // One word for two things no ray needs both of: a radiance ray always searches up to 1e5 (tracer.h:156) and draws random
+    // numbers at its hit; a shadow ray (a continuation through transmitting surfaces) searches up to the distance that is
+    // left to its light sample (shading.h:45) and draws nothing.  96 bytes = six 16-byte pieces instead of seven.
+    union {
+        double tmax_shadow;            // kind == kKindShadow
+        unsigned long long rng;        // kind == kKindRadiance: state of this ray's random stream
+    };
     int pixel;                 // accumulator index inside this part
     short depth;               // remaining depth (tracer.h:149) for radiance rays
     short kind;
+    __device__ __forceinline__ double tmax() const { return kind == kKindShadow ? tmax_shadow : 100000.0; }
 };
-static_assert(sizeof(RayRec) == 112, "RayRec size");
+static_assert(sizeof(RayRec) == 96, "RayRec size");
+constexpr int kRayPieces = sizeof(RayRec) / 16;
 
 struct alignas(16) HitRec {
     double t, bu, bv;
@@ -85,7 +92,7 @@ struct HitQ {
 };
 union RayBits {
     RayRec r;
-    rt_q4 v[7];
+    rt_q4 v[kRayPieces];
     __device__ RayBits() {}
 };
 union HitBits {
@@ -96,14 +103,14 @@ union HitBits {
 __device__ __forceinline__ RayRec ray_load_full(const RayQ& q, unsigned i) {
     RayBits b;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    for (int k = 0; k < kRayPieces; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
     return b.r;
 }
 __device__ __forceinline__ void ray_store(const RayQ q, unsigned i, const RayRec& r) {
     RayBits b;
     b.r = r;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
+    for (int k = 0; k < kRayPieces; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
 }
 __device__ __forceinline__ HitRec hit_load(const HitQ q, unsigned i) {
     HitBits b;
@@ -228,7 +235,8 @@ __device__ __forceinline__ void emit_ray(const RayQ out, unsigned* count, unsign
     r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
     r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
     r.w[0] = w.x; r.w[1] = w.y; r.w[2] = w.z;
-    r.time = time; r.tmax = tmax; r.rng = rng; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
+    r.time = time; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
+    if (kind == kKindShadow) r.tmax_shadow = tmax; else r.rng = rng;
     ray_store(out, slot, r);
 }
 
@@ -253,7 +261,8 @@ __device__ __forceinline__ void emit_ray_at(const RayQ out, unsigned slot, unsig
     r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
     r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
     r.w[0] = w.x; r.w[1] = w.y; r.w[2] = w.z;
-    r.time = time; r.tmax = tmax; r.rng = rng; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
+    r.time = time; r.pixel = pixel; r.depth = (short)depth; r.kind = (short)kind;
+    if (kind == kKindShadow) r.tmax_shadow = tmax; else r.rng = rng;
     ray_store(out, slot, r);
 }
 
@@ -312,7 +321,7 @@ __device__ __forceinline__ RayRec ray_load(const RayQ& q, unsigned i, const DPar
     const double time = r.w[0];
     const unsigned long long rng = (unsigned long long)__double_as_longlong(r.w[1]);
     r.w[0] = r.w[1] = r.w[2] = 1.0;
-    r.time = time; r.tmax = 100000.0; r.rng = rng;
+    r.time = time; r.rng = rng;
     r.pixel = primary_coords(P, q.ck, (long long)i).pixel;
     r.depth = (short)P.max_depth; r.kind = kKindRadiance;
     return r;
@@ -456,7 +465,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 const bool shadow = q.kind == kKindShadow;
                 any_hit = shadow && S.transparent_materials == 0;
                 tmin = shadow ? 0.001 : P.eps_scene;                       // shading.h:45 / tracer.h:152-156
-                const double tmax = shadow ? q.tmax - 0.001 : q.tmax;
+                const double tmax = shadow ? q.tmax_shadow - 0.001 : 100000.0;
                 best = Cand{tmax, -1, 0, 0.0, 0.0};
                 best_order = 0;
                 best_incl = false;
@@ -631,7 +640,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         double refl = r0 + (1.0 - r0) * pow((1.0 - cos_i), 5.0);  // shadow_schlick, shading.h:24-28
         D3 local = cmul(mk(1.0, 1.0, 1.0), ld3(M.diffuse)) * (1.0 - refl);
         if (length(local) < 0.001) return false;
-        emit_ray(E.out, E.count, E.cap, E.overflow, h.p + r.d * 0.001, r.d, cmul(w, local), q.time, q.tmax - h.t, rng.next(), q.pixel,
+        emit_ray(E.out, E.count, E.cap, E.overflow, h.p + r.d * 0.001, r.d, cmul(w, local), q.time, q.tmax_shadow - h.t, 0ull, q.pixel,
                  q.depth, kKindShadow);
         return false;
     }
@@ -1049,7 +1058,7 @@ k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const Hi
             r.time = q.time;
             shadow = q.kind == kKindShadow;
             tmin = shadow ? 0.001 : P.eps_scene;                 // shading.h:45 / tracer.h:152-156
-            tmax = shadow ? q.tmax - 0.001 : q.tmax;
+            tmax = shadow ? q.tmax_shadow - 0.001 : 100000.0;
         }
         Cand best;
         // queued shadow rays are continuations through transmitting surfaces: they need their closest occluder
