@@ -374,7 +374,7 @@ def main():
         dist.barrier()
 
     # one frame at a time (latency setting) and the boundary's own contract -- rt_render into a HOST buffer (main.cpp:242,320)
-    solo_ms, host_ms, traverse_ms_one_frame = None, None, None
+    solo_ms, host_ms, traverse_ms_one_frame, normals_ms = None, None, None, None
     if world == 1:
         torch.cuda.synchronize(dev)
         n_solo = max(5, min(args.steps, 20))
@@ -395,6 +395,17 @@ def main():
         for _ in range(n_solo):
             scene.render(p_host)
         host_ms = (time.perf_counter() - t1) * 1e3 / n_solo
+        # the same frames with --normals (the other flag set of config 2), B per launch like the headline
+        p_n = params.copy()
+        p_n.normals = 1
+        for _ in range(2):
+            scene.render_frames_device(p_n, B, sets[0].slices.data_ptr(), slice_rows=sets[0].max_rows, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(4):
+            scene.render_frames_device(p_n, B, sets[0].slices.data_ptr(), slice_rows=sets[0].max_rows, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        normals_ms = (time.perf_counter() - t1) * 1e3 / (4 * B)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -466,6 +477,8 @@ def main():
             "ms_per_frame_solo": round(solo_ms, 4) if solo_ms else None,
             "Mrays_per_s_solo": round(rays_frame / solo_ms / 1e3, 1) if solo_ms else None,
             "ms_per_frame_host_buffer": round(host_ms, 4) if host_ms else None,
+            "ms_per_frame_normals_flag": round(normals_ms, 4) if normals_ms else None,
+            "Mrays_per_s_normals_flag": round(rays_frame / normals_ms / 1e3, 1) if normals_ms else None,
             "Mrays_per_s_host_buffer": round(rays_frame / host_ms / 1e3, 1) if host_ms else None,
             "roofline": roof,
         }
