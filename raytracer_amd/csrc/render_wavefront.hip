@@ -58,8 +58,20 @@ struct alignas(16) RayRec {
     short kind;
     __device__ __forceinline__ double tmax() const { return kind == kKindShadow ? tmax_shadow : 100000.0; }
 };
-static_assert(sizeof(RayRec) == 96, "RayRec size");
-constexpr int kRayPieces = sizeof(RayRec) / 16;
+// What lies in a queue: the HEAD, four 16-byte pieces, is all a traversal kernel reads -- origin, direction, time and the
+// tmax-or-rng word, the ray's kind being the SIGN of the time (a time is never negative, so nothing is lost: -0.0 is a shadow
+// ray at time 0) -- and all a primary ray has (the rest of its record is implied, see RayQ::primary); the TAIL, two pieces,
+// is what only the shading kernel needs: colour weight, pixel, depth.
+struct alignas(16) RayStore {
+    double o[3], d[3];
+    double time_kind;          // |.| = time; sign set = kKindShadow
+    unsigned long long word;   // tmax_shadow or rng
+    double w[3];
+    int pixel;
+    short depth, pad;
+};
+static_assert(sizeof(RayStore) == 96, "RayStore size");
+constexpr int kRayPieces = sizeof(RayStore) / 16, kRayHeadPieces = 4;
 
 struct alignas(16) HitRec {
     double t, bu, bv;
@@ -75,10 +87,9 @@ struct Chunk {
     int row0, rows;     // rows [row0, row0 + rows) of the launch (compact rows of this part; frame after frame or band by band, k_raygen)
     int s0, ns;         // samples [s0, s0 + ns) of every pixel
 };
-// Primary rays (the queue k_raygen writes: level 0 of every ray tree) are stored SLIM: pieces 0..2 as in RayRec (origin,
-// direction) and piece 3 = (time, rng), 64 bytes instead of 112.  The rest of a primary ray's record is implied -- weight 1,
-// tmax 100000, depth max_depth, kind radiance -- or follows from its index in the queue (pixel: primary_coords), so the
-// three passes over the primary rays (written by k_raygen, read by traversal and by shading) move 144 bytes less per ray.
+// Primary rays (the queue k_raygen writes: level 0 of every ray tree) are stored SLIM: the head of a RayStore alone, 64 bytes
+// instead of 96.  The rest of a primary ray's record is implied -- weight 1, depth max_depth -- or follows from its index in
+// the queue (pixel: primary_coords).
 struct RayQ {
     rt_q4* p;
     unsigned stride;
@@ -91,10 +102,23 @@ struct HitQ {
     unsigned stride;
 };
 union RayBits {
-    RayRec r;
+    RayStore r;
     rt_q4 v[kRayPieces];
     __device__ RayBits() {}
 };
+__device__ __forceinline__ void unpack_head(const RayStore& t, RayRec& r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.o[k] = t.o[k]; r.d[k] = t.d[k]; }
+    r.time = fabs(t.time_kind);
+    r.kind = (short)(__double_as_longlong(t.time_kind) < 0 ? kKindShadow : kKindRadiance);
+    r.rng = t.word;
+}
+__device__ __forceinline__ void pack_head(const RayRec& r, RayStore& t) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t.o[k] = r.o[k]; t.d[k] = r.d[k]; }
+    t.time_kind = r.kind == kKindShadow ? -r.time : r.time;
+    t.word = r.rng;
+}
 union HitBits {
     HitRec h;
     rt_q4 v[2];
@@ -104,11 +128,28 @@ __device__ __forceinline__ RayRec ray_load_full(const RayQ& q, unsigned i) {
     RayBits b;
 #pragma unroll
     for (int k = 0; k < kRayPieces; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
-    return b.r;
+    RayRec r;
+    unpack_head(b.r, r);
+    r.w[0] = b.r.w[0]; r.w[1] = b.r.w[1]; r.w[2] = b.r.w[2];
+    r.pixel = b.r.pixel; r.depth = b.r.depth;
+    return r;
+}
+// What a traversal kernel needs of a queued ray: origin, direction, time, kind, tmax (the head; a primary record is nothing else).
+__device__ __forceinline__ RayRec ray_load_head(const RayQ& q, unsigned i) {
+    RayBits b;
+#pragma unroll
+    for (int k = 0; k < kRayHeadPieces; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    RayRec r;
+    unpack_head(b.r, r);
+    r.w[0] = r.w[1] = r.w[2] = 1.0;
+    r.pixel = 0; r.depth = 0;
+    return r;
 }
 __device__ __forceinline__ void ray_store(const RayQ q, unsigned i, const RayRec& r) {
     RayBits b;
-    b.r = r;
+    pack_head(r, b.r);
+    b.r.w[0] = r.w[0]; b.r.w[1] = r.w[1]; b.r.w[2] = r.w[2];
+    b.r.pixel = r.pixel; b.r.depth = r.depth; b.r.pad = 0;
 #pragma unroll
     for (int k = 0; k < kRayPieces; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
 }
@@ -314,16 +355,9 @@ __device__ __forceinline__ PrimaryCoords primary_coords(const DParams& P, const 
 // A queued ray: a full record, or a slim primary record completed by what is implied.
 __device__ __forceinline__ RayRec ray_load(const RayQ& q, unsigned i, const DParams& P) {
     if (!q.primary) return ray_load_full(q, i);
-    RayBits b;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
-    RayRec r = b.r;   // o, d in place; w[0], w[1] hold (time, rng)
-    const double time = r.w[0];
-    const unsigned long long rng = (unsigned long long)__double_as_longlong(r.w[1]);
-    r.w[0] = r.w[1] = r.w[2] = 1.0;
-    r.time = time; r.rng = rng;
+    RayRec r = ray_load_head(q, i);   // weight 1, radiance
     r.pixel = primary_coords(P, q.ck, (long long)i).pixel;
-    r.depth = (short)P.max_depth; r.kind = kKindRadiance;
+    r.depth = (short)P.max_depth;
     return r;
 }
 
@@ -343,13 +377,13 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
     float py = ((float)c.y + rv) / (float)P.height;
     double time = rng.uniform() * S.shutter_time;
     Ray ray = generate_ray(S.cam, px, py, time, rng);
-    RayBits b;
+    RayBits b;   // a primary record is the head alone
     b.r.o[0] = ray.o.x; b.r.o[1] = ray.o.y; b.r.o[2] = ray.o.z;
     b.r.d[0] = ray.d.x; b.r.d[1] = ray.d.y; b.r.d[2] = ray.d.z;
-    b.r.w[0] = time;                                      // slim record: piece 3 = (time, rng)
-    b.r.w[1] = __longlong_as_double((long long)rng.next());
+    b.r.time_kind = time;
+    b.r.word = rng.next();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out.p[(size_t)k * out.stride + (unsigned)i] = b.v[k];
+    for (int k = 0; k < kRayHeadPieces; ++k) out.p[(size_t)k * out.stride + (unsigned)i] = b.v[k];
 }
 
 // ------------------------------------------------------------------------------------------ k_traverse
@@ -458,7 +492,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
             const unsigned take = min((unsigned)__popcll(idle), avail);
             if (my == kNone && rank < take) {
                 my = chunk_next + rank;
-                const RayRec q = ray_load(rays, my, P);
+                const RayRec q = ray_load_head(rays, my);
                 r.o = ld3(q.o);
                 r.d = ld3(q.d);
                 r.time = q.time;
@@ -1052,7 +1086,7 @@ k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const Hi
         double tmin = 0.0, tmax = 0.0;
         bool shadow = false;
         if (mine) {
-            const RayRec q = ray_load(rays, i, P);
+            const RayRec q = ray_load_head(rays, i);
             r.o = ld3(q.o);
             r.d = ld3(q.d);
             r.time = q.time;
