@@ -1284,7 +1284,9 @@ struct Driver {
     bool allow_grow = true;   // a frame of one chunk whose ray tree outgrows the queues gets larger queues next time (a frame of
                               // several chunks sizes its chunks by the queues: larger queues, larger chunks, the same overflow)
     bool with_shadows() const { return may_emit && P.shadows && S.n_lights > 0; }
-    bool small_scene() const { return S.n_prims <= kSmallScenePrims && getenv("RT_NO_SMALL_SCENE") == nullptr; }
+    // (the environment is looked at once per frame, not once per launch: a 1-spp frame of a small scene is some forty launches)
+    const bool small_env_ok = getenv("RT_NO_SMALL_SCENE") == nullptr;
+    bool small_scene() const { return S.n_prims <= kSmallScenePrims && small_env_ok; }
     // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
     EmitCtx emit_ctx(int qo, int out_level) {
         return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u, 0u, chunk}, tails(out_level), ws.counters + 2, qo >= 0 ? region() : 0u, direct,
