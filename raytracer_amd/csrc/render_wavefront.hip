@@ -1244,7 +1244,7 @@ struct Driver {
     unsigned grid_for(const QIn& in, unsigned long long bound_lanes) {
         unsigned long long blocks = (bound_lanes + kBlock - 1) / kBlock;
         if (!in.counts) return (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(blocks, 0x7fffffffull));
-        blocks = std::min<unsigned long long>(blocks, (unsigned long long)ws.compute_units * 16ull);
+        blocks = std::min<unsigned long long>(blocks, (unsigned long long)ws.compute_units * (unsigned)grid_blocks_per_cu);
         const unsigned k = in.shards;
         return (unsigned)std::max<unsigned long long>(k, (blocks + k - 1) / k * k);
     }
@@ -1260,7 +1260,7 @@ struct Driver {
     template <int F> void launch_traverse_kernel(int q, const QIn& in, unsigned bound, int level) {
         unsigned long long* level_total = reinterpret_cast<unsigned long long*>(ws.counters + kLevelTotal);
         if (small_scene()) {
-            const unsigned blocks = in.counts ? grid_for(in, bound) : std::max(1u, std::min((bound + kBlock - 1) / kBlock, (unsigned)ws.compute_units * 16u));
+            const unsigned blocks = in.counts ? grid_for(in, bound) : std::max(1u, std::min((bound + kBlock - 1) / kBlock, (unsigned)ws.compute_units * (unsigned)grid_blocks_per_cu));
             hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), in, ws.stats, level_total, zero_a, zero_b, K);
             zero_a = zero_b = nullptr;
             return;
@@ -1286,6 +1286,9 @@ struct Driver {
     bool with_shadows() const { return may_emit && P.shadows && S.n_lights > 0; }
     // (the environment is looked at once per frame, not once per launch: a 1-spp frame of a small scene is some forty launches)
     const bool small_env_ok = getenv("RT_NO_SMALL_SCENE") == nullptr;
+    // workgroups per CU of the grids that stride over a queue whose size only the device knows: 8 (16: C1 + shadows 10 % slower,
+    // the 64-spp frames 1-2 %; 4: the same or worse but for C1 + shadows; 2: 20-30 % slower.  RT_GRID_BLOCKS_PER_CU: A/B runs)
+    const int grid_blocks_per_cu = getenv("RT_GRID_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("RT_GRID_BLOCKS_PER_CU"))) : 8;
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && small_env_ok; }
     // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
     EmitCtx emit_ctx(int qo, int out_level) {
