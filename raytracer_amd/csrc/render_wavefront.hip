@@ -211,7 +211,10 @@ __device__ __forceinline__ void bundle_store(const BundleQ q, unsigned i, const 
 // `region` entries, each with a tail of its own (on a 128-byte line of its own), and a wave emits into the shard its
 // input came from (or, reading a dense queue, into shard wave % shards): the children of a wave stay together, the load
 // per shard is bounded (one shard's input times the fan-out), and 32 tails take 32 times the atomics.
-constexpr unsigned kShards = 32;          // shards of a queue when the scene is small (frames of many small levels)
+#ifndef RT_SHARDS
+#define RT_SHARDS 32
+#endif
+constexpr unsigned kShards = RT_SHARDS;          // shards of a queue when the scene is small (frames of many small levels)
 constexpr unsigned kCountStride = 32;     // words between the tails of neighbouring shards
 constexpr unsigned kCountArrays = 96;     // one array of tails per ray-tree level (reused modulo this)
 constexpr size_t kShardCountBytes = (size_t)(kCountArrays + 1) * kShards * kCountStride * sizeof(unsigned);   // + 1: the bundles' tails
