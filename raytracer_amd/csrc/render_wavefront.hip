@@ -1541,7 +1541,18 @@ hipError_t prepare_workspace(const DScene& scene, const DParams& params, hipStre
     // queues mean few batches, i.e. few launches and few host round trips per level: HBM is there to be used.
     const char* env = getenv("RT_QUEUE_RAYS");
     const size_t env_cap = env ? strtoull(env, nullptr, 10) : 0;
-    const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : std::max(kDefaultMaxQueueRays, ws.grown_capacity), size_t(1) << 31);   // slots are 32-bit
+    // Default ceiling: 2^26 rays per queue; 2^27 where the frame can use it and the device has the room (a workspace of such
+    // queues is ~70 GB: three queues with their hit records and the bundles) -- a frame of many samples is cut into chunks whose
+    // every ray-tree level is a few launches and whose end is a read-back, so twice the queue is half of those (4K x 16 spp
+    // with two area lights: 101 -> 92 ms).
+    size_t default_cap = kDefaultMaxQueueRays;
+    if (env_cap < 4096 && ws.capacity < 2 * kDefaultMaxQueueRays && npix * (size_t)params.spp * (may_emit ? first_level_fanout(scene, params) : 1) > kDefaultMaxQueueRays) {
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && free_bytes >= (size_t(160) << 30)) default_cap = 2 * kDefaultMaxQueueRays;
+    } else if (ws.capacity >= 2 * kDefaultMaxQueueRays) {
+        default_cap = 2 * kDefaultMaxQueueRays;   // this stream already holds such queues
+    }
+    const size_t max_cap = std::min(env_cap >= 4096 ? env_cap : std::max(default_cap, ws.grown_capacity), size_t(1) << 31);   // slots are 32-bit
     const size_t fan = may_emit ? first_level_fanout(scene, params) : 1;
     size_t want = kMinQueueRays;
     const char* head = getenv("RT_QUEUE_HEADROOM");   // queues this many times larger than the first level needs (deep ray trees)
