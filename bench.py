@@ -200,11 +200,23 @@ def other_configs(dev):
                     torch.cuda.synchronize(dev)
                     ms16 = e0.elapsed_time(e1) / 32
                     del buf16
+                ms_acc = None
+                if rng == "seeded" and spp > 1 and w * h >= 3840 * 2160:
+                    # config 5 proper is 64 such passes added up in HBM (rt_accumulate_device runs them two at a time)
+                    d_sum = torch.zeros((h, w, 3), dtype=torch.float64, device=dev)
+                    sc.accumulate_device(p, d_sum.data_ptr(), 0, 2, stream=stream.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    t_acc = time.perf_counter()
+                    sc.accumulate_device(p, d_sum.data_ptr(), 2, 4, stream=stream.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    ms_acc = (time.perf_counter() - t_acc) * 1e3 / 4
+                    del d_sum
                 sc.close()
                 k = shares.get(name, {})
                 res.append({"config": label, "fixture": name, "resolution": [w, h], "spp": spp, "rays_per_frame": int(st.rays),
                             "ms": round(ms, 3), "Mrays_per_s": round(st.rays / ms / 1e3, 1), "frames_timed": reps,
                             "ms_per_frame_16_frames_per_call": round(ms16, 3) if ms16 else None, "sampling": rng,
+                            "ms_per_pass_in_rt_accumulate_device": round(ms_acc, 3) if ms_acc else None,
                             "dominant_kernel": k.get("kernel"), "dominant_kernel_fraction": k.get("fraction"),
                             "dominant_kernel_source": k.get("source")})
                 if k.get("valu"):   # VALU issue and lane fractions of the frame's kernels, from the committed PMC passes

@@ -1152,7 +1152,9 @@ __global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restr
     const int i = blockIdx.x * kBlock + threadIdx.x;   // interleaved RGB out, planes in
     if (i >= n3) return;
     const double v = accum[(size_t)(i % 3) * (size_t)(n3 / 3) + i / 3] * (1.0 / spp);
-    out[i] = add ? out[i] + v : v;   // add: a pass of a progressive render joins the running sum in HBM
+    // add 1: a pass of a progressive render joins the running sum in HBM; 2: so does a pass on another stream at the same time
+    if (add == 2) unsafeAtomicAdd(&out[i], v);
+    else out[i] = add ? out[i] + v : v;
 }
 
 // Progressive render: the sum of `passes` pass averages -> the picture so far (average, tone map, truncate: main.cpp:308-320).
@@ -1618,7 +1620,7 @@ hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, si
 }
 
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, bool add_linear) {
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, int add_linear) {
     // pixels of the output: `frames` slices of slice_rows rows each (one frame of part_rows rows unless rt_render_frames_device calls)
     const size_t npix = (size_t)params.frames * params.slice_rows * params.width;
     const int launch_rows = params.frames * params.part_rows;   // rows of primary rays
@@ -1701,7 +1703,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (D.err != hipSuccess) return D.err;
     if (d_linear)
         hipLaunchKernelGGL(k_resolve_linear, dim3((unsigned)((npix * 3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_linear,
-                           (int)(npix * 3), params.spp, add_linear ? 1 : 0);
+                           (int)(npix * 3), params.spp, add_linear);
     else if (!D.direct)
         hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
                            params.spp, params.tonemap);
