@@ -831,14 +831,14 @@ int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d
             DParams q = base;
             for (int k = 1; k < passes && helper_error == hipSuccess; k += 2) {
                 q.seed = params->seed + first_pass + static_cast<uint64_t>(k);
-                helper_error = launch_render_wavefront(scene->d, q, nullptr, nullptr, helper, ws2, d_sum, 2);
+                helper_error = launch_render_wavefront(scene->d, q, nullptr, nullptr, helper, ws2, d_sum, 2, true);
             }
         });
     }
     hipError_t e = hipSuccess;
     for (int k = 0; k < passes && e == hipSuccess; k += two ? 2 : 1) {
         dp.seed = params->seed + first_pass + static_cast<uint64_t>(k);
-        e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, ws, d_sum, two ? 2 : 1);
+        e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, ws, d_sum, two ? 2 : 1, two);   // (two passes at a time: no chunk pairs inside them)
     }
     if (two) {
         odd.join();

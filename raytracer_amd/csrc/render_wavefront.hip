@@ -27,9 +27,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "device_rt.h"
@@ -1194,6 +1196,7 @@ struct Driver {
     bool may_emit = true;   // false: no launch of k_shade can queue a ray
     size_t max_capacity = 0;   // RT_QUEUE_RAYS
     uint8_t* direct = nullptr;   // see EmitCtx::direct
+    double* accum = nullptr;     // the frame's accumulators (the workspace's own, or the partner's frame's: see WavefrontWorkspace::partner)
     hipError_t err = hipSuccess;
 
     bool ok(hipError_t e) {
@@ -1307,9 +1310,9 @@ struct Driver {
         const unsigned long long bound = std::min<unsigned long long>((unsigned long long)n * (unsigned)S.n_lights, ws.capacity) * 2ull * (unsigned)P.shadow_samples;
         const unsigned blocks = grid_for(in, bound);
         if (small_scene())
-            hipLaunchKernelGGL((k_shadow<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, ws.accum, ws.stats);
+            hipLaunchKernelGGL((k_shadow<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, accum, ws.stats);
         else
-            hipLaunchKernelGGL((k_shadow<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, ws.accum, ws.stats);
+            hipLaunchKernelGGL((k_shadow<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, accum, ws.stats);
     }
     void shadow(unsigned n, int qo, int out_level) {
         if (!with_shadows()) return;
@@ -1324,13 +1327,13 @@ struct Driver {
         const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi)));
         const QIn& v = in;
         if (may_emit && small_scene())
-            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
         else if (may_emit)
-            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, true, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
         else if (small_scene())
-            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
         else
-            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, ws.accum);
+            hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
     }
     void traverse(int q, const QIn& in, unsigned bound, int level) {
         if (trav_variant == 0) launch_traverse<kSpheres>(q, in, bound, level);
@@ -1476,6 +1479,13 @@ struct Driver {
 }  // namespace
 
 void wavefront_workspace_free(WavefrontWorkspace& ws) {
+    if (ws.partner) {
+        wavefront_workspace_free(*ws.partner);
+        delete ws.partner;
+        ws.partner = nullptr;
+    }
+    if (ws.partner_stream) (void)hipStreamDestroy(ws.partner_stream);
+    ws.partner_stream = nullptr;
     if (!ws.fixed) {
         for (void* p : ws.queues) (void)hipFree(p);
         for (void* p : ws.hit_buffers) (void)hipFree(p);
@@ -1536,7 +1546,7 @@ hipError_t ensure_small_buffers(WavefrontWorkspace& ws) {
 
 // Sizes and allocates what a frame needs of an owned (not fixed) workspace.
 hipError_t prepare_workspace(const DScene& scene, const DParams& params, hipStream_t stream, WavefrontWorkspace& ws, size_t npix,
-                             bool may_emit, size_t* max_queue_rays) {
+                             bool may_emit, size_t* max_queue_rays, bool need_accum = true) {
     hipError_t e;
     // Queue capacity: what one chunk of primary rays and its children need, up to RT_QUEUE_RAYS (default 2^26 rays =
     // 9.7 GB per queue; a frame that needs more is rendered in chunks of rows x samples and batches of rays).  Large
@@ -1571,7 +1581,7 @@ hipError_t prepare_workspace(const DScene& scene, const DParams& params, hipStre
     if ((e = ensure_small_buffers(ws)) != hipSuccess) return e;
     if (may_emit && params.shadows && scene.n_lights > 0 && !ws.bundles &&
         (e = hipMalloc(&ws.bundles, ws.capacity * sizeof(Bundle))) != hipSuccess) return e;
-    if (ws.accum_pixels < npix) {
+    if (need_accum && ws.accum_pixels < npix) {
         if (ws.accum) (void)hipFree(ws.accum);
         ws.accum = nullptr;
         ws.accum_pixels = 0;
@@ -1620,7 +1630,7 @@ hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, si
 }
 
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, int add_linear) {
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, int add_linear, bool no_partner) {
     // pixels of the output: `frames` slices of slice_rows rows each (one frame of part_rows rows unless rt_render_frames_device calls)
     const size_t npix = (size_t)params.frames * params.slice_rows * params.width;
     const int launch_rows = params.frames * params.part_rows;   // rows of primary rays
@@ -1638,6 +1648,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     Driver D{scene, params, ws, stream, 0, 0};
     D.may_emit = may_emit;
     D.max_capacity = max_queue_rays;
+    D.accum = ws.accum;
     if (!D.may_emit && params.spp == 1 && !d_linear) D.direct = d_rgb8;
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
@@ -1671,27 +1682,95 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     // RT_SYNC_LEVELS=1 keeps the level-by-level path (A/B runs, tests).
     const int levels = tree_levels(scene, params);
     D.allow_grow = rows_per_chunk >= launch_rows && ns >= params.spp;
+    std::vector<Chunk> chunks;
+    for (int row0 = 0; row0 < launch_rows; row0 += rows_per_chunk)
+        for (int s0 = 0; s0 < params.spp; s0 += ns)
+            chunks.push_back(Chunk{row0, std::min(rows_per_chunk, launch_rows - row0), s0, std::min(ns, params.spp - s0)});
+    // one chunk through driver X: primary rays, then its ray tree.  0 = done, 1 = a level outgrew its queue, -1 = error
+    auto run_chunk = [&](Driver& X, const Chunk& ck, bool optimistic) -> int {
+        const long long n = (long long)ck.rows * W * ck.ns;
+        const int q = X.acquire();
+        if (q < 0) return -1;
+        X.chunk = ck;
+        hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, X.stream, scene, params, X.rays(q, 0), n,
+                           X.ws.counters + kNextBase);
+        if (!optimistic) {
+            X.process(q, (unsigned)n, 0);
+            return X.err == hipSuccess ? 0 : -1;
+        }
+        const int lr = X.run_levels(q, (unsigned)n, levels);
+        if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] capacity %zu grow %zu -> %s\n", X.ws.capacity, X.ws.grow, lr == 0 ? "done" : "overflow");
+        return X.err != hipSuccess ? -1 : lr;
+    };
+    // A frame of many chunks renders them TWO AT A TIME: a chunk is a dozen levels of launches, the deep ones a few microseconds
+    // of work each, and a read-back the host waits for, ~0.4 ms whatever the chunk's size; the odd chunks go through a second
+    // set of queues (ws.partner) on a stream of its own, enqueued by a second host thread, and add into the same accumulators,
+    // so that one chunk's small launches and round trip hide behind the other's large launches (RT_ONE_CHUNK_AT_A_TIME: A/B).
+    unsigned long long partner_rays = 0;
+    bool partner_used = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool optimistic = attempt == 0 && may_emit && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
         bool overflowed = false;
-        for (int row0 = 0; row0 < launch_rows && D.err == hipSuccess && !overflowed; row0 += rows_per_chunk) {
-            const int rows = std::min(rows_per_chunk, launch_rows - row0);
-            for (int s0 = 0; s0 < params.spp && D.err == hipSuccess && !overflowed; s0 += ns) {
-                Chunk ck{row0, rows, s0, std::min(ns, params.spp - s0)};
-                const long long n = (long long)rows * W * ck.ns;
-                int q = D.acquire();
-                if (q < 0) break;
-                D.chunk = ck;
-                hipLaunchKernelGGL(k_raygen, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scene, params, D.rays(q, 0), n,
-                                   ws.counters + kNextBase);
-                if (optimistic) {
-                    const int lr = D.run_levels(q, (unsigned)n, levels);
-                    if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] capacity %zu grow %zu -> %s\n", ws.capacity, ws.grow, lr == 0 ? "done" : "overflow");
-                    overflowed = lr != 0;
-                } else {
-                    D.process(q, (unsigned)n, 0);
-                }
+        bool pairs = optimistic && chunks.size() >= 4 && !ws.fixed && !params.count_tests && !no_partner && getenv("RT_ONE_CHUNK_AT_A_TIME") == nullptr;
+        if (pairs && !ws.partner) {
+            size_t free_bytes = 0, total_bytes = 0;
+            const size_t workspace_bytes = ws.capacity * (4 * (sizeof(RayStore) + sizeof(HitRec)) + sizeof(Bundle));
+            if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < workspace_bytes + (size_t(24) << 30)) pairs = false;
+            else {
+                ws.partner = new WavefrontWorkspace();
+                if (hipStreamCreateWithFlags(&ws.partner_stream, hipStreamNonBlocking) != hipSuccess) { delete ws.partner; ws.partner = nullptr; pairs = false; }
             }
+        }
+        if (pairs) {
+            WavefrontWorkspace& w2 = *ws.partner;
+            size_t mq2 = 0;
+            w2.grow = ws.grow;
+            w2.grown_capacity = ws.grown_capacity;
+            if ((e = prepare_workspace(scene, params, ws.partner_stream, w2, npix, may_emit, &mq2, false)) != hipSuccess) return e;
+            if (w2.capacity != ws.capacity) pairs = false;   // (cannot happen: same frame, same rules)
+        }
+        if (pairs) {
+            WavefrontWorkspace& w2 = *ws.partner;
+            hipStream_t s2 = ws.partner_stream;
+            Driver D2{scene, params, w2, s2, 0, 0};
+            D2.may_emit = D.may_emit; D2.max_capacity = D.max_capacity; D2.accum = ws.accum; D2.direct = D.direct;
+            D2.variant = D.variant; D2.trav_variant = D.trav_variant; D2.shadow_variant = D.shadow_variant;
+            D2.traverse_blocks = D.traverse_blocks; D2.K = D.K; D2.allow_grow = false;
+            if (w2.events_used + 64 > kMaxTimedEvents) w2.events_used = 0;
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if ((e = hipEventCreateWithFlags(&ev0, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev1, hipEventDisableTiming)) != hipSuccess) { (void)hipEventDestroy(ev0); return e; }
+            (void)hipEventRecord(ev0, stream);            // the accumulators are cleared before either stream adds to them
+            (void)hipStreamWaitEvent(s2, ev0, 0);
+            (void)hipMemsetAsync(w2.stats + 7, 0, sizeof(unsigned long long), s2);
+            int device = 0;
+            (void)hipGetDevice(&device);
+            std::atomic<bool> stop{false};
+            int result2 = 0;
+            std::thread odd([&]() {
+                if (hipSetDevice(device) != hipSuccess) { result2 = -1; stop = true; return; }
+                for (size_t i = 1; i < chunks.size() && !stop.load(); i += 2) {
+                    result2 = run_chunk(D2, chunks[i], true);
+                    if (result2 != 0) stop = true;
+                }
+            });
+            int result1 = 0;
+            for (size_t i = 0; i < chunks.size() && !stop.load(); i += 2) {
+                result1 = run_chunk(D, chunks[i], true);
+                if (result1 != 0) stop = true;
+            }
+            odd.join();
+            (void)hipEventRecord(ev1, s2);
+            (void)hipStreamWaitEvent(stream, ev1, 0);      // whatever follows on the caller's stream sees both halves
+            (void)hipEventDestroy(ev0);
+            (void)hipEventDestroy(ev1);
+            if (result1 < 0 || result2 < 0) return D.err != hipSuccess ? D.err : (D2.err != hipSuccess ? D2.err : hipErrorUnknown);
+            overflowed = result1 == 1 || result2 == 1;
+            if (w2.levels_overflowed) { ws.levels_overflowed = true; ws.overflowed_scene = scene.serial; w2.levels_overflowed = false; }
+            partner_rays = D2.rays_traced;
+            partner_used = !overflowed;
+        } else {
+            for (size_t i = 0; i < chunks.size() && D.err == hipSuccess && !overflowed; ++i) overflowed = run_chunk(D, chunks[i], optimistic) == 1;
         }
         if (!overflowed || D.err != hipSuccess) break;
         if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
@@ -1699,6 +1778,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
         ws.events_used = first_event;
         D.rays_traced = 0;
+        partner_rays = 0;
     }
     if (D.err != hipSuccess) return D.err;
     if (d_linear)
@@ -1725,6 +1805,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     } else if (d_counters) {
         hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, D.rays_traced, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull,
                            ws.stats + 7);
+        if (partner_used)
+            hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, partner_rays, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull,
+                               ws.partner->stats + 7);
     }
     return hipGetLastError();
 }

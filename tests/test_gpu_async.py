@@ -182,6 +182,63 @@ def test_a_level_that_outgrows_its_queue_restarts_the_frame_level_by_level(gpu, 
     assert 0.0 < st.traverse_ms < 3.0 * st_ref.traverse_ms + 1.0
 
 
+def _render_counted(scene_file, params, monkeypatch, one_at_a_time):
+    """One frame through rt_render_device without the statistics variant of the kernels (a frame that counts its tests
+    renders its chunks one at a time): the picture and the rays the call adds to its device counters."""
+    if one_at_a_time:
+        monkeypatch.setenv("RT_ONE_CHUNK_AT_A_TIME", "1")
+    else:
+        monkeypatch.delenv("RT_ONE_CHUNK_AT_A_TIME", raising=False)
+    dev = torch.device("cuda", 0)
+    scene = rt.Scene(scene_file)
+    stream = torch.cuda.Stream(dev)
+    buf = torch.zeros((scene.height, scene.width, 3), dtype=torch.uint8, device=dev)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    for _ in range(2):   # the second frame reuses both sets of queues
+        scene.render_device(params, buf.data_ptr(), d_counters_ptr=counters.data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    rt.release_workspaces()
+    scene.close()
+    return buf.cpu().numpy(), int(counters[0].item()) // 2
+
+
+@pytest.mark.parametrize("name", ["c1_shadows_fresnel", "own_glass_env"])
+def test_chunks_two_at_a_time_render_the_same_frame(gpu, name, monkeypatch):
+    """A frame of four chunks or more renders them two at a time, the odd ones through a second set of queues on a
+    stream and host thread of the library's own (render_wavefront.hip: ws.partner): same frame and ray count as one chunk
+    at a time and as one big queue.  own_glass_env's third level outgrows a 4096-ray queue: both halves stop and the
+    frame starts over level by level."""
+    scene_file, params, golden = helpers.load_case(name)
+    scene = rt.Scene(scene_file)
+    ref, st_ref = scene.render(params, stats=True)
+    scene.close()
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    one, rays_one = _render_counted(scene_file, params, monkeypatch, True)
+    two, rays_two = _render_counted(scene_file, params, monkeypatch, False)
+    assert rays_one == int(st_ref.rays) and rays_two == int(st_ref.rays)
+    for img in (one, two):
+        mx, nd, _ = helpers.diff_stats(img, ref)
+        assert mx <= 1 and nd <= 0.001 * img.size
+        assert helpers.diff_stats(img, golden)[0] <= 1
+
+
+def test_chunks_two_at_a_time_with_many_samples(gpu, monkeypatch):
+    """16 spp through 4096-ray queues: chunks of one pixel row band split by sample batches add into the same pixels
+    from both streams (FP64 atomics)."""
+    scene_file, params, hi, lo, psnr_ref = helpers.load_stochastic("st_soft_shadows", 16, 5)
+    scene = rt.Scene(scene_file)
+    ref = scene.render(params)
+    scene.close()
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    one, rays_one = _render_counted(scene_file, params, monkeypatch, True)
+    two, rays_two = _render_counted(scene_file, params, monkeypatch, False)
+    assert rays_one == rays_two and rays_two > 0
+    for img in (one, two):
+        mx, nd, _ = helpers.diff_stats(img, ref)
+        assert mx <= 1 and nd <= 0.01 * img.size
+
+
 def test_render_on_torchs_default_stream_is_ordered_with_torch_work(gpu):
     """hip_stream NULL is HIP's null stream == torch's default stream: a torch op enqueued right after the render reads the
     finished frame without any synchronisation in between (the multi-GPU recipe of INTEGRATION.md relies on this)."""
