@@ -202,7 +202,7 @@ def other_configs(dev):
                     del buf16
                 ms_acc = None
                 if rng == "seeded" and spp > 1 and w * h >= 3840 * 2160:
-                    # config 5 proper is 64 such passes added up in HBM (rt_accumulate_device runs them two at a time)
+                    # config 5 proper is 64 such passes added up in HBM (rt_accumulate_device: one pass after the other, chunks two at a time)
                     d_sum = torch.zeros((h, w, 3), dtype=torch.float64, device=dev)
                     sc.accumulate_device(p, d_sum.data_ptr(), 0, 2, stream=stream.cuda_stream)
                     torch.cuda.synchronize(dev)

@@ -334,10 +334,10 @@ int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void
  * samples each -- pass k of the series with seed params->seed + first_pass + k (RT_RNG_SEEDED) -- and ADDS each pass's
  * linear average to d_sum_f64 (3 doubles per pixel of this part, compact tile order, zeroed by the caller before the
  * first pass), asynchronously on `hip_stream`: nothing crosses PCIe until the caller wants a picture or a checkpoint
- * (sum + pass count).  With two passes or more the library renders them two at a time: the odd passes on a stream and a
- * host thread of its own (with their own ray queues), behind whatever `hip_stream` held at the call, both adding into the
- * sum with FP64 atomics, and `hip_stream` waits for that stream before the call returns its work to the caller (the order of
- * the additions, and with it the last bits of the sum, may differ from run to run; RT_ACCUMULATE_ONE_STREAM=1: one by one).
+ * (sum + pass count).  The passes run one after the other on `hip_stream`; within a pass of many samples the chunks of
+ * primary rays are rendered two at a time like those of any large frame (a second set of ray queues on a stream and a host
+ * thread of the library's own, both adding into the pass's accumulators with FP64 atomics: the order of the additions, and
+ * with it the last bits of the sum, may differ from run to run; RT_ONE_CHUNK_AT_A_TIME=1: one by one).
  * rt_resolve_sum_device turns the sum of `passes` passes into the bytes Image::setPixel would hold:
  * divide, tone map, truncate (main.cpp:308-320, tracer.h:23-54,297-308). */
 int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d_sum_f64, uint64_t first_pass, int passes, void* hip_stream);

@@ -13,7 +13,6 @@
 #include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <utility>
 #include <vector>
 
@@ -801,52 +800,15 @@ int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     WavefrontWorkspace& ws = *workspace_of(st, true);
     double* d_sum = static_cast<double*>(d_sum_f64);
-    // Passes are independent, and a pass of many samples is a row of chunks, each a dozen levels of small launches and a
-    // read-back the host waits for: two passes at a time, the odd ones on a stream of the library's own (with its own ray queues,
-    // driven by a thread of its own), hide those behind each other's large launches (4K x 16 spp with two area lights: 92 -> 82 ms
-    // per pass).  Both add into the sum with FP64 atomics; the caller's stream waits for the helper's at the end.
-    const bool two = passes >= 2 && getenv("RT_ACCUMULATE_ONE_STREAM") == nullptr;
-    hipStream_t helper = nullptr;
-    hipEvent_t start = nullptr, done = nullptr;
-    if (two) {
-        static std::mutex helper_mutex;
-        static std::map<int, hipStream_t> helpers;   // one per device, kept (its workspace is pooled like any stream's)
-        std::lock_guard<std::mutex> lock(helper_mutex);
-        hipStream_t& h = helpers[g_dev.device];
-        if (!h) HIP_TRY(hipStreamCreateWithFlags(&h, hipStreamNonBlocking));
-        helper = h;
-        HIP_TRY(hipEventCreateWithFlags(&start, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(start, st));              // whatever the caller enqueued before (the sum's initialisation) comes first
-        HIP_TRY(hipStreamWaitEvent(helper, start, 0));
-    }
-    hipError_t helper_error = hipSuccess;
-    std::thread odd;
-    if (two) {
-        WavefrontWorkspace& ws2 = *workspace_of(helper, true);
-        const DParams base = dp;
-        const int device = g_dev.device;
-        odd = std::thread([&, base, device]() {
-            if (hipSetDevice(device) != hipSuccess) { helper_error = hipErrorInvalidDevice; return; }
-            DParams q = base;
-            for (int k = 1; k < passes && helper_error == hipSuccess; k += 2) {
-                q.seed = params->seed + first_pass + static_cast<uint64_t>(k);
-                helper_error = launch_render_wavefront(scene->d, q, nullptr, nullptr, helper, ws2, d_sum, 2, true);
-            }
-        });
-    }
+    // One pass after the other on the caller's stream, each added to the sum by the resolve kernel.  A pass of many samples is a
+    // row of chunks, which launch_render_wavefront renders two at a time (a second set of queues, a stream and a host thread of
+    // the library's own): that hides the small launches and the read-back of one chunk behind the other's large launches, which
+    // is what running two PASSES at a time did before (4K x 16 spp with two area lights: 92 -> 82 ms per pass either way; two
+    // passes at a time on top of chunk pairs would hold four sets of queues).
     hipError_t e = hipSuccess;
-    for (int k = 0; k < passes && e == hipSuccess; k += two ? 2 : 1) {
+    for (int k = 0; k < passes && e == hipSuccess; ++k) {
         dp.seed = params->seed + first_pass + static_cast<uint64_t>(k);
-        e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, ws, d_sum, two ? 2 : 1, two);   // (two passes at a time: no chunk pairs inside them)
-    }
-    if (two) {
-        odd.join();
-        (void)hipEventRecord(done, helper);
-        (void)hipStreamWaitEvent(st, done, 0);
-        (void)hipEventDestroy(start);
-        (void)hipEventDestroy(done);
-        if (e == hipSuccess) e = helper_error;
+        e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, ws, d_sum, 1);
     }
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;

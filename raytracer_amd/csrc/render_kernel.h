@@ -54,8 +54,7 @@ void wavefront_workspace_free(WavefrontWorkspace& ws);
 // d_linear != NULL: instead of RGB8, write the per-pixel average before tone mapping as 3 doubles per pixel (add_linear:
 // add it to what d_linear holds -- progressive accumulation on the device).
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear = nullptr, int add_linear = 0,
-                                   bool no_partner = false);   // no_partner: never render chunks two at a time (the caller overlaps frames itself)
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear = nullptr, int add_linear = 0);
 // Sum of `passes` linear pass averages (interleaved RGB doubles) -> average, tone map, 8 bits (main.cpp:308-320).
 hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, size_t npix, int tonemap, uint8_t* d_rgb8, hipStream_t stream);
 

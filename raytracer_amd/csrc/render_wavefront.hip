@@ -935,11 +935,14 @@ constexpr int kInlineSegments = 6;
 #define RT_SHADOW_WAVES 4         // waves per SIMD asked of the register allocator: 3 measured 5-8 % faster than 2 on the analytic
 #endif                            // variants and 4 another 2-3.5 % on the 64-spp frames (5: spills, x 1.2 - 1.4 slower); the variant with
                                   // the ray marcher and the texture paths spills already at 3 (x 1.6) and stays at 2
+#ifndef RT_SHADOW_COMPLEX_WAVES
+#define RT_SHADOW_COMPLEX_WAVES 2 // ... of the variant with the ray marcher and the environment (3 and 4 spill: C4 7.5 -> 8.9 / 8.0 ms)
+#endif
 #ifndef RT_SHADOW_TEX_WAVES
 #define RT_SHADOW_TEX_WAVES 2     // ... of the analytic + textures variant
 #endif
 template <int F, bool SMALL>
-__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_ENV)) ? 2 : (F & RT_FEAT_TEXTURE) ? RT_SHADOW_TEX_WAVES : RT_SHADOW_WAVES)
+__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_ENV)) ? RT_SHADOW_COMPLEX_WAVES : (F & RT_FEAT_TEXTURE) ? RT_SHADOW_TEX_WAVES : RT_SHADOW_WAVES)
 k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn in, const EmitCtx E0, double* __restrict__ accum,
          unsigned long long* __restrict__ stats) {
     __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
@@ -1154,9 +1157,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restr
     const int i = blockIdx.x * kBlock + threadIdx.x;   // interleaved RGB out, planes in
     if (i >= n3) return;
     const double v = accum[(size_t)(i % 3) * (size_t)(n3 / 3) + i / 3] * (1.0 / spp);
-    // add 1: a pass of a progressive render joins the running sum in HBM; 2: so does a pass on another stream at the same time
-    if (add == 2) unsafeAtomicAdd(&out[i], v);
-    else out[i] = add ? out[i] + v : v;
+    out[i] = add ? out[i] + v : v;   // add: a pass of a progressive render joins the running sum in HBM
 }
 
 // Progressive render: the sum of `passes` pass averages -> the picture so far (average, tone map, truncate: main.cpp:308-320).
@@ -1630,7 +1631,7 @@ hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, si
 }
 
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
-                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, int add_linear, bool no_partner) {
+                                   hipStream_t stream, WavefrontWorkspace& ws, double* d_linear, int add_linear) {
     // pixels of the output: `frames` slices of slice_rows rows each (one frame of part_rows rows unless rt_render_frames_device calls)
     const size_t npix = (size_t)params.frames * params.slice_rows * params.width;
     const int launch_rows = params.frames * params.part_rows;   // rows of primary rays
@@ -1711,7 +1712,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool optimistic = attempt == 0 && may_emit && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
         bool overflowed = false;
-        bool pairs = optimistic && chunks.size() >= 4 && !ws.fixed && !params.count_tests && !no_partner && getenv("RT_ONE_CHUNK_AT_A_TIME") == nullptr;
+        bool pairs = optimistic && chunks.size() >= 4 && !ws.fixed && !params.count_tests && getenv("RT_ONE_CHUNK_AT_A_TIME") == nullptr;
         if (pairs && !ws.partner) {
             size_t free_bytes = 0, total_bytes = 0;
             const size_t workspace_bytes = ws.capacity * (4 * (sizeof(RayStore) + sizeof(HitRec)) + sizeof(Bundle));

@@ -1,5 +1,5 @@
 """scratch/accumulate_timing.py: config 5's loop -- passes of 16 spp of the 4K motion-blur frame added up in HBM by rt_accumulate_device --
-with the passes two at a time (default) and one at a time (RT_ACCUMULATE_ONE_STREAM=1)."""
+with chunks two at a time (default) and one at a time (RT_ONE_CHUNK_AT_A_TIME=1)."""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,5 +22,5 @@ with tempfile.TemporaryDirectory() as scratch:
     scene.accumulate_device(p, d_sum.data_ptr(), 2, n, stream=st.cuda_stream)
     torch.cuda.synchronize()
     print("%d passes of %d spp at %dx%d: %.2f ms per pass (%s)" % (n, spp, w, h, (time.perf_counter() - t) * 1e3 / n,
-          "one at a time" if os.environ.get("RT_ACCUMULATE_ONE_STREAM") else "two at a time"))
+          "chunks one at a time" if os.environ.get("RT_ONE_CHUNK_AT_A_TIME") else "chunks two at a time"))
     scene.close()
