@@ -248,8 +248,19 @@ def main():
         else:
             dist.init_process_group(args.backend)
     rt.init(local_rank)
+    native_exchange = None
     if world > 1 and args.backend == "nccl":
-        init_comm(dev)   # the library's own RCCL communicator: slices travel by rt_gather_frames (comm.hip)
+        # the library's own RCCL communicator: slices travel by rt_gather_frames (comm.hip).  Should it fail to come up on any
+        # rank, every rank falls back to torch.distributed's gather (RCCL too) + index_select, and the line says so.
+        ok = 1
+        try:
+            init_comm(dev)
+        except Exception as e:   # noqa: BLE001
+            ok = 0
+            print("bench.py: rank %d: the library's communicator did not come up (%s)" % (rank, str(e)[:200]), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native_exchange = bool(flag.item())
 
     cfg = workloads.default_config()
     scene_desc = workloads.bvh_stress_scene(args.spheres, args.width, args.height)
@@ -274,7 +285,7 @@ def main():
         n_streams = S
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)   # RT_N_COUNTERS
-    sets = [FrameGather(W, H, args.tile_rows, dev, frames=B) for _ in range(S)]   # slices [B, max_rows, W, 3]; frames on rank 0
+    sets = [FrameGather(W, H, args.tile_rows, dev, frames=B, native=native_exchange) for _ in range(S)]   # slices [B, max_rows, W, 3]; frames on rank 0
     batch_events = []
 
     # All exchanges are issued on ONE stream of their own, in batch order (operations of a communicator stay ordered whatever
@@ -476,7 +487,7 @@ def main():
             "config": {"workload": "C2: %d random ellipsoids (default_rng(12345)), %dx%d, Whitted 1 spp, default flags, BVH on"
                                    % (args.spheres, W, H),
                        "partition": "interleaved row tiles of %d rows over %d GPU(s), u8 slices gathered to rank 0 (%s)"
-                                    % (args.tile_rows, world, "rt_gather_frames: RCCL send/recv + k_deinterleave" if args.backend == "nccl" else args.backend + " REHEARSAL, not a measurement"),
+                                    % (args.tile_rows, world, ("rt_gather_frames: RCCL send/recv + k_deinterleave" if native_exchange is not False else "torch.distributed gather over RCCL + index_select: the library's communicator did not come up") if args.backend == "nccl" else args.backend + " REHEARSAL, not a measurement"),
                        "rays_per_frame": rays_frame, "node_fetches_per_ray": round(nodes_frame / max(1, rays_frame), 2),
                        "box_tests_per_ray": round(boxes_frame / max(1, rays_frame), 2),
                        "prim_tests_per_ray": round(prims_frame / max(1, rays_frame), 2), "sampling": "seeded: a random position inside the pixel per ray as in main.cpp:288-302, frame f of a launch with seed + f" if args.sampling == "seeded" else "deterministic (RT_RNG_D0: pixel centres)",

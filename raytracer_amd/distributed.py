@@ -57,7 +57,7 @@ class FrameGather:
     1080p frame is 0.78 MB and ~0.12 ms of rendering, so a collective per frame is bound by its launch and host cost, not
     by xGMI; one per batch of frames is 1/frames as many, each frames times larger."""
 
-    def __init__(self, width, height, tile_rows, device, frames=1):
+    def __init__(self, width, height, tile_rows, device, frames=1, native=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.width, self.height, self.tile_rows, self.batch = width, height, tile_rows, frames
@@ -67,6 +67,8 @@ class FrameGather:
         self.gathered, self.gather_buffer, self.frames, self.frame, self.index, self._parts = None, None, None, None, None, None
         # the library's exchange (RCCL + k_deinterleave) whenever its communicator spans this group
         self.native = self.world > 1 and self.slices.is_cuda and rt.comm_world() == self.world and rt.comm_rank() == self.rank
+        if native is False:   # the caller found the library's communicator missing on some rank: torch.distributed's gather on all
+            self.native = False
         if self.rank == 0 and self.native:
             self.frames = torch.empty((frames, height, width, 3), dtype=torch.uint8, device=device)
             self.frame = self.frames[0]
