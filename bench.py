@@ -397,7 +397,7 @@ def main():
         dist.barrier()
 
     # one frame at a time (latency setting) and the boundary's own contract -- rt_render into a HOST buffer (main.cpp:242,320)
-    solo_ms, host_ms, traverse_ms_one_frame, normals_ms = None, None, None, None
+    solo_ms, host_ms, traverse_ms_one_frame, normals_ms, fp32_variant = None, None, None, None, None
     if world == 1:
         torch.cuda.synchronize(dev)
         n_solo = max(5, min(args.steps, 20))
@@ -429,9 +429,32 @@ def main():
             scene.render_frames_device(p_n, B, sets[0].slices.data_ptr(), slice_rows=sets[0].max_rows, stream=streams[0].cuda_stream)
         torch.cuda.synchronize(dev)
         normals_ms = (time.perf_counter() - t1) * 1e3 / (4 * B)
+        # the throughput variant (RT_SCHEDULE_WAVEFRONT_FP32: FP32 sphere test; NOT the parity mode, never the headline value): its
+        # rate on the same frames and its mismatch count against the parity frame ("reported with its mismatch count")
+        p_f = params.copy()
+        p_f.schedule = rt.RT_SCHEDULE_WAVEFRONT_FP32
+        parity = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        fast = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        scene.render_device(params, parity.data_ptr(), stream=streams[0].cuda_stream)
+        scene.render_device(p_f, fast.data_ptr(), stream=streams[0].cuda_stream)
+        for _ in range(2):
+            scene.render_frames_device(p_f, B, sets[0].slices.data_ptr(), slice_rows=sets[0].max_rows, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(4):
+            scene.render_frames_device(p_f, B, sets[0].slices.data_ptr(), slice_rows=sets[0].max_rows, stream=streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        fp32_ms = (time.perf_counter() - t1) * 1e3 / (4 * B)
+        diff = (parity.to(torch.int16) - fast.to(torch.int16)).abs().amax(dim=2)
+        fp32_variant = {"what": "RT_SCHEDULE_WAVEFRONT_FP32: the sphere test of the traversal in FP32 (throughput variant, not the parity mode)",
+                        "ms_per_frame": round(fp32_ms, 4), "Mrays_per_s": round(rays_frame / fp32_ms / 1e3, 1),
+                        "pixels_off_by_more_than_1": int((diff > 1).sum().item()), "pixels_off_by_1": int((diff == 1).sum().item()),
+                        "max_abs_diff": int(diff.max().item()), "pixels": W * H}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
+        if fp32_variant:
+            fp32_variant["speedup_vs_parity"] = round(ms_per_step / fp32_variant["ms_per_frame"], 3)
         value = rays_frame * args.steps / elapsed / 1e6
         boxes_rank = int(c[1])
         # per launch of the dominant kernel = B frames of this rank
@@ -502,6 +525,7 @@ def main():
             "ms_per_frame_host_buffer": round(host_ms, 4) if host_ms else None,
             "ms_per_frame_normals_flag": round(normals_ms, 4) if normals_ms else None,
             "Mrays_per_s_normals_flag": round(rays_frame / normals_ms / 1e3, 1) if normals_ms else None,
+            "fp32_variant": fp32_variant,
             "Mrays_per_s_host_buffer": round(rays_frame / host_ms / 1e3, 1) if host_ms else None,
             "roofline": roof,
         }

@@ -134,7 +134,14 @@ typedef struct RtSceneDesc {
 enum { RT_TONEMAP_NONE = 0, RT_TONEMAP_REINHARD = 1, RT_TONEMAP_ACES = 2, RT_TONEMAP_FILMIC = 3 }; /* main.cpp:68 */
 enum {
     RT_SCHEDULE_WAVEFRONT = 0,  /* ray queues in HBM: persistent traversal kernel + shading kernel per level (default) */
-    RT_SCHEDULE_MEGAKERNEL = 1  /* one launch, one lane per pixel with a bounded pending-ray stack                   */
+    RT_SCHEDULE_MEGAKERNEL = 1, /* one launch, one lane per pixel with a bounded pending-ray stack                   */
+    /* The THROUGHPUT variant of the wavefront schedule ("FP32 is the throughput variant, reported with its
+     * mismatch count"): the hit-deciding primitive tests of the hierarchy traversal run in FP32 where a kernel variant has
+     * them -- today the sphere test of spheres-only scenes (BASELINE config 2); every other scene renders exactly as with
+     * RT_SCHEDULE_WAVEFRONT.  NOT the parity mode: silhouette pixels may differ from the reference by more than one level
+     * (tests/test_gpu_fp32.py and bench.py's `fp32_variant` count them).  rt_render, rt_render_device and
+     * rt_render_frames_device accept it. */
+    RT_SCHEDULE_WAVEFRONT_FP32 = 2
 };
 enum {
     RT_RNG_D0 = 0,      /* deterministic: every uniform 0.5, ball/disk samples 0 (oracle mode "d0") */

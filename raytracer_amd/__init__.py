@@ -21,7 +21,7 @@ RT_SHAPE_SPHERE, RT_SHAPE_PLANE, RT_SHAPE_CUBE = 0, 1, 2
 RT_SHAPE_COMPLEX_SPHERE, RT_SHAPE_COMPLEX_CUBE, RT_SHAPE_COMPLEX_PLANE = 3, 4, 5
 RT_TONEMAP_NONE, RT_TONEMAP_REINHARD, RT_TONEMAP_ACES, RT_TONEMAP_FILMIC = 0, 1, 2, 3
 RT_RNG_D0, RT_RNG_SEEDED = 0, 1
-RT_SCHEDULE_WAVEFRONT, RT_SCHEDULE_MEGAKERNEL = 0, 1
+RT_SCHEDULE_WAVEFRONT, RT_SCHEDULE_MEGAKERNEL, RT_SCHEDULE_WAVEFRONT_FP32 = 0, 1, 2
 RT_ERR_INVALID, RT_ERR_IO, RT_ERR_DEVICE, RT_ERR_NOT_INIT, RT_ERR_LIMIT = -1, -2, -3, -4, -5
 TONEMAP_BY_NAME = {"none": 0, "reinhard": 1, "aces": 2, "filmic": 3}  # main.cpp:198-216
 

@@ -673,7 +673,8 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     if (p->shadows && p->shadow_samples <= 0) return fail(RT_ERR_INVALID, "shadow_samples must be >= 1 when shadows are on");
     if (p->glossy_samples < 0) return fail(RT_ERR_INVALID, "glossy_samples must be >= 0");
     if (p->glossy_samples > 60) return fail(RT_ERR_LIMIT, "glossy_samples is limited to 60 (one bit per reflection ray of a hit in the shading kernel)");
-    if (p->schedule != RT_SCHEDULE_WAVEFRONT && p->schedule != RT_SCHEDULE_MEGAKERNEL) return fail(RT_ERR_INVALID, "unknown schedule");
+    if (p->schedule != RT_SCHEDULE_WAVEFRONT && p->schedule != RT_SCHEDULE_MEGAKERNEL && p->schedule != RT_SCHEDULE_WAVEFRONT_FP32)
+        return fail(RT_ERR_INVALID, "unknown schedule");
     // Megakernel pending-ray stack bound: the first hit may queue glossy_samples + 1 rays, every deeper level at most one more.
     if (p->schedule == RT_SCHEDULE_MEGAKERNEL && std::max(p->max_depth, 0) + p->glossy_samples + 2 > kRayStackDepth)
         return fail(RT_ERR_LIMIT, "max_depth + glossy_samples exceeds the pending-ray stack (" + std::to_string(kRayStackDepth) + ")");
@@ -688,6 +689,7 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     d.tile_rows = tile; d.part_index = parts > 1 ? p->part_index : 0; d.part_count = parts;
     d.part_rows = rt_part_rows(scene->height, tile, d.part_index, parts);
     d.count_tests = collect ? 1 : 0;
+    d.fp32_tests = p->schedule == RT_SCHEDULE_WAVEFRONT_FP32 ? 1 : 0;
     d.frames = 1; d.slice_rows = d.part_rows;
     d.exposure = p->exposure; d.eps_scene = p->eps_scene; d.eps_triangle = p->eps_triangle; d.eps_march = p->eps_march;
     d.eps_shadow = p->eps_shadow; d.step_multiplier = p->step_multiplier;
@@ -695,6 +697,26 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     std::memcpy(d.ambient_light, p->ambient_light, 24);
     d.seed = p->seed;
     *o = d;
+    return RT_OK;
+}
+
+// RT_SCHEDULE_WAVEFRONT_FP32 on a spheres-only scene: the FP32 copy of the transforms, made on the device by the first such
+// frame (on its stream, ahead of its kernels; later frames on other streams wait for it once) and kept with the scene.
+static int ensure_xforms32(rt_scene_t scene, const DParams& dp, hipStream_t st) {
+    if (!dp.fp32_tests || scene->d.features != RT_FEAT_SPHERE || scene->d.n_xforms <= 0) return RT_OK;
+    std::lock_guard<std::mutex> lock(g_wf_mutex);
+    if (!scene->d.xforms32) {
+        float* p = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(scene->d.n_xforms) * 16 * sizeof(float));
+        if (e == hipSuccess) e = launch_make_xforms32(scene->d.xforms, scene->d.n_xforms, p, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);   // once per scene: every stream may use the copy from here on
+        if (e != hipSuccess) {
+            if (p) (void)hipFree(p);
+            return fail(RT_ERR_DEVICE, std::string("FP32 transforms: ") + hipGetErrorString(e));
+        }
+        scene->allocations.push_back(p);
+        scene->d.xforms32 = p;
+    }
     return RT_OK;
 }
 
@@ -709,6 +731,7 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
     if (dp.part_rows == 0) return RT_OK;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if ((rc = ensure_xforms32(scene, dp, st))) return rc;
     hipError_t e;
     if (params->schedule == RT_SCHEDULE_MEGAKERNEL)
         e = launch_render_mega(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
@@ -730,7 +753,7 @@ int rt_render_frames_device(rt_scene_t scene, const RtRenderParams* params, int 
     DParams dp;
     int rc = make_dparams(scene, params, 0, &dp);
     if (rc) return rc;
-    if (params->schedule != RT_SCHEDULE_WAVEFRONT) return fail(RT_ERR_INVALID, "rt_render_frames_device renders with the wavefront schedule");
+    if (params->schedule == RT_SCHEDULE_MEGAKERNEL) return fail(RT_ERR_INVALID, "rt_render_frames_device renders with the wavefront schedule");
     if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
     if (slice_rows == 0) slice_rows = dp.part_rows;
     if (slice_rows < dp.part_rows) return fail(RT_ERR_INVALID, "slice_rows is smaller than the rows this part owns (rt_part_rows)");
@@ -740,6 +763,7 @@ int rt_render_frames_device(rt_scene_t scene, const RtRenderParams* params, int 
     dp.frames = frames;
     dp.slice_rows = slice_rows;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if ((rc = ensure_xforms32(scene, dp, st))) return rc;
     hipError_t e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
                                            *workspace_of(st, true));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));

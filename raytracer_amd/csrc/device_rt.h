@@ -445,6 +445,55 @@ __device__ __forceinline__ bool tie_new_wins(bool new_incl, int new_order, bool 
     return new_incl ? (new_order > cur_order) : (new_order < cur_order);
 }
 
+// The FP32 sphere test of the throughput variant (RT_SCHEDULE_WAVEFRONT_FP32, spheres-only scenes): same roots as
+// sphere.cpp:44-90 in exact arithmetic, evaluated around the point of closest approach -- with the ray origin hundreds of
+// radii away, o.o - 1 of the textbook form loses the sphere in the rounding of o.o (2^-24 * |o|^2), whereas the closest
+// approach p = o + tc d is a point near the unit sphere whose error is 2^-24 * |o|.  Hit or miss and t are decided in FP32:
+// silhouette pixels and a few t ties may come out differently from the FP64 parity path, which is what the variant's
+// mismatch count reports.
+struct Ray32 {
+    float o[3], d[3], time;
+};
+__device__ __forceinline__ Ray32 make_ray32(const Ray& r) {
+    return Ray32{{(float)r.o.x, (float)r.o.y, (float)r.o.z}, {(float)r.d.x, (float)r.d.y, (float)r.d.z}, (float)r.time};
+}
+template <bool COUNT>
+__device__ __forceinline__ void test_sphere32(const DScene& S, const DParams& P, const Ray32& r, int prim, float tmin, Cand& best,
+                                              int& best_order, bool& best_incl, Counters& C) {
+    if (COUNT && P.count_tests) C.prims++;
+    const float4* X = reinterpret_cast<const float4*>(S.xforms32) + 4 * (size_t)prim;
+    const float4 m0 = X[0], m1 = X[1], m2 = X[2], vw = X[3];   // rows of world -> object; velocity xyz, inv33
+    const float ox = fmaf(-vw.x, r.time, r.o[0]), oy = fmaf(-vw.y, r.time, r.o[1]), oz = fmaf(-vw.z, r.time, r.o[2]);
+    float qx = fmaf(m0.x, ox, fmaf(m0.y, oy, fmaf(m0.z, oz, m0.w)));
+    float qy = fmaf(m1.x, ox, fmaf(m1.y, oy, fmaf(m1.z, oz, m1.w)));
+    float qz = fmaf(m2.x, ox, fmaf(m2.y, oy, fmaf(m2.z, oz, m2.w)));
+    if (vw.w != 0.f && vw.w != 1.f) {   // matrix4x4.cpp:85-90
+        const float iw = 1.f / vw.w;
+        qx *= iw; qy *= iw; qz *= iw;
+    }
+    const float dx = fmaf(m0.x, r.d[0], fmaf(m0.y, r.d[1], m0.z * r.d[2]));
+    const float dy = fmaf(m1.x, r.d[0], fmaf(m1.y, r.d[1], m1.z * r.d[2]));
+    const float dz = fmaf(m2.x, r.d[0], fmaf(m2.y, r.d[1], m2.z * r.d[2]));
+    const float a = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float ia = __builtin_amdgcn_rcpf(a);
+    const float tc = -fmaf(qx, dx, fmaf(qy, dy, qz * dz)) * ia;          // parameter of the closest approach to the centre
+    const float px = fmaf(tc, dx, qx), py = fmaf(tc, dy, qy), pz = fmaf(tc, dz, qz);
+    const float h2 = 1.f - fmaf(px, px, fmaf(py, py, pz * pz));          // (half chord)^2 in object units
+    if (!(h2 >= 0.f)) return;
+    const float s = __builtin_amdgcn_sqrtf(h2 * ia);
+    const float tmax = (float)best.t;
+    float root = tc - s;
+    if (root < tmin) root = tc + s;                                       // sphere.cpp:60-66
+    if (root < tmin || root > tmax) return;
+    const double t = (double)root;
+    // spheres accept t == t_max (sphere.cpp:83): among equal t the later primitive in visit order wins (tie_new_wins)
+    if (t < best.t || best.prim < 0 || prim > best_order) {
+        best = Cand{t, prim, 0, 0.0, 0.0};
+        best_order = prim;
+        best_incl = true;
+    }
+}
+
 // One primitive against the ray; updates `best` when it is the new closest hit.
 template <int F, bool COUNT = true>
 __device__ __forceinline__ void test_prim(const DScene& S, const DParams& P, const Ray& r, int prim, int order, double tmin,

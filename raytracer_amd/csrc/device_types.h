@@ -136,6 +136,8 @@ struct DScene {
     const float* prim_boxes;      // scenes of at most kSmallScenePrims primitives: world box of primitive k, widened like the node
                                   // boxes, as lo xyz, hi xyz (FP32); else null
     const float* env;             // float RGB rows in file order, may be null
+    const float* xforms32;        // FP32 copy of the transforms for RT_SCHEDULE_WAVEFRONT_FP32 (16 floats each: rows 0..2 of inv, then
+                                  // velocity xyz and inv33), made on the first such frame of a spheres-only scene; else null
     int32_t env_present, env_w, env_h;
     int32_t n_prims, n_nodes, n_lights;
     int32_t n_xforms, n_quads, n_materials;
@@ -155,7 +157,8 @@ enum : int32_t {
     RT_FEAT_COMPLEX = 4,
     RT_FEAT_TEXTURE = 8,    // any texture or bump map
     RT_FEAT_ENV = 16,
-    RT_FEAT_SPHERE = 32
+    RT_FEAT_SPHERE = 32,
+    RT_FEAT_FP32 = 64      // never in DScene::features: selects the kernel variant with FP32 primitive tests (spheres-only scenes)
 };
 
 // Render parameters as the kernel sees them.
@@ -166,7 +169,7 @@ struct DParams {
     int32_t glossy_samples, shadow_samples, march_steps, rng_mode;
     int32_t tile_rows, part_index, part_count, part_rows;  // part_rows = rows this part owns
     int32_t count_tests;   // also count node / primitive tests
-    int32_t pad;
+    int32_t fp32_tests;    // RT_SCHEDULE_WAVEFRONT_FP32: the throughput variant (FP32 primitive tests where a kernel variant has them)
     // Several frames of the same scene in one launch (rt_render_frames_device): frame f is rendered with seed + f into the
     // slice that begins f * slice_rows rows into the output.  frames = 1, slice_rows = part_rows for every other entry point.
     int32_t frames, slice_rows;

@@ -55,6 +55,8 @@ void wavefront_workspace_free(WavefrontWorkspace& ws);
 // add it to what d_linear holds -- progressive accumulation on the device).
 hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, uint8_t* d_rgb8, unsigned long long* d_counters,
                                    hipStream_t stream, WavefrontWorkspace& ws, double* d_linear = nullptr, int add_linear = 0);
+// FP32 copy of n transforms for the kernel variants with FP32 primitive tests (DScene::xforms32): 16 floats each.
+hipError_t launch_make_xforms32(const DXform* xforms, int n, float* out, hipStream_t stream);
 // Sum of `passes` linear pass averages (interleaved RGB doubles) -> average, tone map, 8 bits (main.cpp:308-320).
 hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, size_t npix, int tonemap, uint8_t* d_rgb8, hipStream_t stream);
 

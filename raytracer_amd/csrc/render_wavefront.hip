@@ -398,7 +398,12 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
 #ifndef RT_TRAVERSE_WAVES_SPHERES
 #define RT_TRAVERSE_WAVES_SPHERES 5   // ... for the spheres-only variant, which fits 96 registers (its workgroups' LDS stacks
 #endif                                // fit five to a CU with 14 entries per lane): 7 % faster than 4 on the launch of 16 C2 frames
-template <int F> constexpr int traverse_waves() { return F == RT_FEAT_SPHERE ? RT_TRAVERSE_WAVES_SPHERES : RT_TRAVERSE_WAVES; }
+#ifndef RT_TRAVERSE_WAVES_FP32
+#define RT_TRAVERSE_WAVES_FP32 5      // ... for the spheres-only variant with the FP32 sphere test
+#endif
+template <int F> constexpr int traverse_waves() {
+    return F == (RT_FEAT_SPHERE | RT_FEAT_FP32) ? RT_TRAVERSE_WAVES_FP32 : F == RT_FEAT_SPHERE ? RT_TRAVERSE_WAVES_SPHERES : RT_TRAVERSE_WAVES;
+}
 #ifndef RT_NODE_VOTE
 #define RT_NODE_VOTE 24           // run an interior-node step while at least this many lanes want one
 #endif
@@ -411,6 +416,9 @@ template <int F> constexpr int traverse_waves() { return F == RT_FEAT_SPHERE ? R
 #endif
 #ifndef RT_LEAF_VOTE
 #define RT_LEAF_VOTE 8            // test the parked leaves once this many lanes hold one
+#endif
+#ifndef RT_LEAF_VOTE_FP32
+#define RT_LEAF_VOTE_FP32 8       // ... in the variant with the FP32 sphere test
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 64               // rays a wave reserves from the queue per atomic
@@ -460,7 +468,9 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
     unsigned chunk_next = 0, chunk_end = 0;            // this wave's reserved rays [chunk_next, chunk_end)
     const unsigned xcd = blockIdx.x & (kXcds - 1u);     // workgroups are dealt to the XCDs round-robin
     unsigned victim = 0;                               // shares of the queue found empty so far
+    constexpr bool kFp32 = (F & RT_FEAT_FP32) != 0;   // the throughput variant: FP32 sphere test (test_sphere32), the ray kept in FP32
     Ray r{mk(0, 0, 0), mk(0, 0, 1), 0.0};
+    Ray32 r32{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}, 0.f};
     RayF rf{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0u, 0u, 0u}};
     double tmin = 0.0;
     float tmin32 = 0.f, tmax32 = 0.f;   // tmax32 follows best.t (rounded up)
@@ -501,6 +511,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 r.o = ld3(q.o);
                 r.d = ld3(q.d);
                 r.time = q.time;
+                if constexpr (kFp32) r32 = make_ray32(r);
                 const bool shadow = q.kind == kKindShadow;
                 any_hit = shadow && S.transparent_materials == 0;
                 tmin = shadow ? 0.001 : P.eps_scene;                       // shading.h:45 / tracer.h:152-156
@@ -520,7 +531,11 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                         tmax32 = __double2float_ru(tmax);
                         if (box_test32(S.root_lo, S.root_hi, rf, tmin32, tmax32, e)) cur = S.root_ref;
                     } else {  // --no-bvh: the list in scene-file order (hittable_list.cpp:8-33)
-                        for (int i = 0; i < S.n_prims; ++i) test_prim<F, COUNT>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+                        if constexpr (kFp32) {
+                            for (int i = 0; i < S.n_prims; ++i) test_sphere32<COUNT>(S, P, r32, S.file_order[i], (float)tmin, best, best_order, best_incl, C);
+                        } else {
+                            for (int i = 0; i < S.n_prims; ++i) test_prim<F, COUNT>(S, P, r, S.file_order[i], i, tmin, best, best_order, best_incl, C);
+                        }
                     }
                 }
             }
@@ -540,7 +555,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
         bool is_node = static_cast<unsigned>(cur) < static_cast<unsigned>(kDone);
         int nn = __popcll(__ballot(is_node));
         const int nl = __popcll(__ballot(pend != 0));
-        if (nn != 0 && nl < RT_LEAF_VOTE && (nn >= RT_NODE_VOTE || nn >= nl)) {
+        if (nn != 0 && nl < (kFp32 ? RT_LEAF_VOTE_FP32 : RT_LEAF_VOTE) && (nn >= RT_NODE_VOTE || nn >= nl)) {
             // ---- interior nodes; while most of the wave still wants one, stay here (no scheduling work per step)
             do {
 #ifdef RT_LANE_STATS
@@ -572,8 +587,13 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
             if (pend != 0) {
                 const int code = ~pend;
                 const int first = code >> 1;
-                test_prim<F, COUNT>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
-                if (code & 1) test_prim<F, COUNT>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+                if constexpr (kFp32) {
+                    test_sphere32<COUNT>(S, P, r32, first, (float)tmin, best, best_order, best_incl, C);
+                    if (code & 1) test_sphere32<COUNT>(S, P, r32, first + 1, (float)tmin, best, best_order, best_incl, C);
+                } else {
+                    test_prim<F, COUNT>(S, P, r, first, first, tmin, best, best_order, best_incl, C);
+                    if (code & 1) test_prim<F, COUNT>(S, P, r, first + 1, first + 1, tmin, best, best_order, best_incl, C);
+                }
                 tmax32 = __double2float_ru(best.t);
                 pend = 0;
                 // The shading of an occluded shadow ray only asks whether its occluder transmits: with opaque materials
@@ -1151,6 +1171,15 @@ __global__ void k_sum_counts(const unsigned* __restrict__ counts, const unsigned
     }
 }
 
+// DScene::xforms32 from DScene::xforms (round to nearest).
+__global__ void __launch_bounds__(kBlock) k_make_xforms32(const DXform* __restrict__ x, const int n, float* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;   // one float per thread
+    if (i >= n * 16) return;
+    const DXform& X = x[i >> 4];
+    const int k = i & 15;
+    out[i] = (float)(k < 12 ? X.inv[k] : k < 15 ? X.vel[k - 12] : X.inv33);
+}
+
 // Linear radiance (the average before tone mapping) for float output and progressive accumulation.
 __global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const int n3,
                                                            const int spp, const int add) {
@@ -1337,7 +1366,8 @@ struct Driver {
             hipLaunchKernelGGL((k_shade<F, false, false>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
     }
     void traverse(int q, const QIn& in, unsigned bound, int level) {
-        if (trav_variant == 0) launch_traverse<kSpheres>(q, in, bound, level);
+        if (trav_variant == 0 && P.fp32_tests && S.xforms32 && !small_scene()) launch_traverse<kSpheres | RT_FEAT_FP32>(q, in, bound, level);
+        else if (trav_variant == 0) launch_traverse<kSpheres>(q, in, bound, level);
         else if (trav_variant == 1) launch_traverse<kAnalytic>(q, in, bound, level);
         else launch_traverse<kFull>(q, in, bound, level);
     }
@@ -1627,6 +1657,12 @@ hipError_t launch_resolve_sum(const double* d_sum, unsigned long long passes, si
     if (npix == 0) return hipSuccess;
     hipLaunchKernelGGL(k_resolve_sum, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_sum, d_rgb8, npix,
                        1.0 / (double)(passes ? passes : 1ull), tonemap_mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_make_xforms32(const DXform* xforms, int n, float* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_make_xforms32, dim3((unsigned)(((size_t)n * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, xforms, n, out);
     return hipGetLastError();
 }
 
