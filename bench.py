@@ -213,8 +213,13 @@ def other_configs(dev):
                     del d_sum
                 sc.close()
                 k = shares.get(name, {})
+                traced = int(st.rays) - int(st.rays_coincident)
                 res.append({"config": label, "fixture": name, "resolution": [w, h], "spp": spp, "rays_per_frame": int(st.rays),
-                            "ms": round(ms, 3), "Mrays_per_s": round(st.rays / ms / 1e3, 1), "frames_timed": reps,
+                            # rays as the reference counts them (its world.intersect calls); of these, the 2 x shadow_samples rays of a hit
+                            # towards a light of radius 0 are one and the same ray, which is traced once: both counts, both rates
+                            "rays_traced_per_frame": traced,
+                            "ms": round(ms, 3), "Mrays_per_s": round(st.rays / ms / 1e3, 1), "Mrays_per_s_traced": round(traced / ms / 1e3, 1),
+                            "frames_timed": reps,
                             "ms_per_frame_16_frames_per_call": round(ms16, 3) if ms16 else None, "sampling": rng,
                             "ms_per_pass_in_rt_accumulate_device": round(ms_acc, 3) if ms_acc else None,
                             "dominant_kernel": k.get("kernel"), "dominant_kernel_fraction": k.get("fraction"),

@@ -189,6 +189,9 @@ typedef struct RtStats {
     double traverse_ms;       /* of which: the BVH traversal kernel launches (wavefront schedule)   */
     double total_ms;          /* wall time of the call incl. copies                                */
     uint64_t nodes_fetched;   /* 64-byte hierarchy nodes fetched (each holds up to four child boxes; same)   */
+    uint64_t rays_coincident; /* of `rays`: queries the reference repeats with the very same ray -- the 2 x shadow_samples rays of a hit
+                                 towards a light of radius 0 (shading.h:31-36,154,192) -- which the wavefront schedule traces once
+                                 and counts as the reference does: rays - rays_coincident closest-hit searches were executed */
 } RtStats;
 
 typedef struct rt_scene_s* rt_scene_t;
@@ -290,7 +293,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
  * the null stream, which is also PyTorch's default stream, so whatever the caller enqueues there afterwards is ordered
  * behind the render): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice
  * a rank hands to the RCCL gather.  d_counters may be NULL or a device pointer to RT_N_COUNTERS (8) uint64 (rays, box tests,
- * primitive tests, nanoseconds spent in the traversal kernel, hierarchy nodes fetched, most nodes fetched by one ray, most scheduler iterations of one wave, reserved) that the
+ * primitive tests, nanoseconds spent in the traversal kernel, hierarchy nodes fetched, most nodes fetched by one ray, most scheduler iterations of one wave, rays counted but not traced: RtStats.rays_coincident) that the
  * kernel adds into (the two maxima are max-combined); collect_counters!=0 additionally counts node/primitive tests. */
 int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* d_counters,
                      int collect_counters, void* hip_stream);

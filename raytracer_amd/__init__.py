@@ -92,7 +92,7 @@ class RtRenderParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
                 ("kernel_ms", C.c_double), ("traverse_ms", C.c_double), ("total_ms", C.c_double),
-                ("nodes_fetched", C.c_uint64)]
+                ("nodes_fetched", C.c_uint64), ("rays_coincident", C.c_uint64)]
 
 
 class RtBuildInfo(C.Structure):

@@ -691,6 +691,7 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     d.count_tests = collect ? 1 : 0;
     d.fp32_tests = p->schedule == RT_SCHEDULE_WAVEFRONT_FP32 ? 1 : 0;
     d.frames = 1; d.slice_rows = d.part_rows;
+    d.trace_coincident = std::getenv("RT_TRACE_COINCIDENT_RAYS") != nullptr ? 1 : 0;
     d.exposure = p->exposure; d.eps_scene = p->eps_scene; d.eps_triangle = p->eps_triangle; d.eps_march = p->eps_march;
     d.eps_shadow = p->eps_shadow; d.step_multiplier = p->step_multiplier;
     std::memcpy(d.background, p->background, 24);
@@ -919,6 +920,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
         stats->nodes_visited = counters[1];
         stats->prims_tested = counters[2];
         stats->nodes_fetched = counters[4];
+        stats->rays_coincident = counters[7];
         stats->kernel_ms = ms;
         stats->traverse_ms = static_cast<double>(counters[3]) * 1e-6;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -975,6 +977,7 @@ int rt_render_gathered(rt_scene_t scene, const RtRenderParams* params, uint8_t* 
         stats->nodes_visited = counters[1];
         stats->prims_tested = counters[2];
         stats->nodes_fetched = counters[4];
+        stats->rays_coincident = counters[7];
         stats->kernel_ms = ms;
         stats->traverse_ms = static_cast<double>(counters[3]) * 1e-6;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -173,6 +173,8 @@ struct DParams {
     // Several frames of the same scene in one launch (rt_render_frames_device): frame f is rendered with seed + f into the
     // slice that begins f * slice_rows rows into the output.  frames = 1, slice_rows = part_rows for every other entry point.
     int32_t frames, slice_rows;
+    int32_t trace_coincident;   // RT_TRACE_COINCIDENT_RAYS=1 (A/B runs, tests): k_shadow traces every one of the coincident rays of a point light
+    int32_t pad;
     double exposure, eps_scene, eps_triangle, eps_march, eps_shadow, step_multiplier;
     double background[3];
     double ambient_light[3];

@@ -968,7 +968,16 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
     __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
     __shared__ SceneStage<SMALL> staged;
     const DScene S = staged.stage(S0);
-    const unsigned per = 2u * (unsigned)P.shadow_samples;
+    // The 2 x samples rays of a bundle towards a light of radius 0 are one and the same ray (shading.h:31-36 only moves the
+    // target when the light has a size): it is traced ONCE, carries the sum of the weights and counts as the 2 x samples
+    // closest-hit queries the reference makes.  With point lights only, a bundle is one lane; otherwise the other lanes of such
+    // a bundle sit out.
+    const unsigned per_ref = 2u * (unsigned)P.shadow_samples;
+    bool point_lights_only = true;
+    for (int l = 0; l < S.n_lights; ++l) point_lights_only = point_lights_only && S.lights[l].radius == 0.0;
+    const bool merge = P.trace_coincident == 0;
+    point_lights_only = point_lights_only && merge;
+    const unsigned per = point_lights_only ? 1u : per_ref;
     // this workgroup's shard of the bundles (block_span in 64-bit lanes: a bundle is `per` lanes)
     const unsigned shard = blockIdx.x % in.shards;
     const unsigned long long n = (unsigned long long)min(in.counts[shard * kCountStride], in.region) * per;
@@ -980,6 +989,7 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
     stack.lds = &stack_mem[0][threadIdx.x];
     stack.stride = kBlock;
     Counters C{0u, 0u, 0u, 0u};
+    unsigned coincident = 0u;   // queries of the reference that were not traced because they coincide with one that was
     const bool any_hit = S.transparent_materials == 0;
     // the grid is sized by the machine, not by the bound on the bundles (most levels of a ray tree hold far fewer than
     // the bound): every workgroup strides over the rays that are really there
@@ -987,17 +997,22 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
         const unsigned long long i = base + threadIdx.x;
         D3 c = mk(0.0, 0.0, 0.0);
         int pixel = -1 - lane;
-        const bool mine = i < n;
+        bool mine = i < n;
         Bundle b;
         Ray sr{mk(0, 0, 0), mk(0, 0, 1), 0.0};
         D3 wt = mk(0, 0, 0);
         double dist = 0.0;
         Rng rng{0ull, true};
+        unsigned copies = 1u;   // rays of the reference this lane's ray stands for
         if (mine) {
             const unsigned bi = (unsigned)(i / per), k = (unsigned)(i % per);
             b = bundle_load(bundles, bi);
             const DLight& L = S.lights[b.light];
             const bool specular = k >= (unsigned)P.shadow_samples;
+            if (merge && L.radius == 0.0) {
+                copies = per_ref;
+                if (k != 0u) mine = false;
+            }
             // this ray's own random stream (the reference draws the samples of a hit one after the other from one
             // generator; the estimator only needs them independent)
             rng = Rng{b.rng ^ ((unsigned long long)(k + 1u) * 0xD1B54A32D192ED03ull), P.rng_mode == RT_RNG_D0};
@@ -1009,10 +1024,11 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
             dist = length(d);
             d = normalize(d);
             sr = Ray{ld3(b.org), d, b.time};
-            wt = specular ? ld3(b.ws) : ld3(b.wd);
+            wt = copies > 1u ? (ld3(b.wd) + ld3(b.ws)) * (double)P.shadow_samples : specular ? ld3(b.ws) : ld3(b.wd);
         }
         bool going = mine, reached = false;
         int seg = 0;
+        const unsigned rays_before = C.rays;
         for (; seg < kInlineSegments; ++seg) {
             if (SMALL) { if (__ballot(going) == 0ull) break; }
             else if (!going) break;
@@ -1040,11 +1056,16 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
             sr.o = h.p + sr.d * 0.001;
             dist = dist - h.t;
         }
+        coincident += (C.rays - rays_before) * (copies - 1u);
+        C.rays += (C.rays - rays_before) * (copies - 1u);
         if (reached) {
             c = wt;
             pixel = b.pixel;
-        } else if (going) {   // still inside a stack of transmitting surfaces: the next level's queue takes over
-            emit_ray(E.out, E.count, E.cap, E.overflow, sr.o, sr.d, wt, b.time, dist, rng.next(), b.pixel, b.depth, kKindShadow);
+        } else if (going) {   // still inside a stack of transmitting surfaces: the next level's queue takes over (a ray that stands
+                              // for several goes on as that many, so that the queries of the queued part are counted as the reference's)
+            const D3 share = copies > 1u ? wt * (1.0 / (double)copies) : wt;
+            for (unsigned k = 0; k < copies; ++k)
+                emit_ray(E.out, E.count, E.cap, E.overflow, sr.o, sr.d, share, b.time, dist, rng.next(), b.pixel, b.depth, kKindShadow);
         }
         const int left = __shfl_up(pixel, 1);
         const unsigned long long heads = __ballot(lane == 0 || left != pixel);
@@ -1062,6 +1083,7 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         rays += __shfl_down(rays, off);
+        coincident += __shfl_down(coincident, off);
         if (P.count_tests) {
             nodes += __shfl_down(nodes, off);
             prims += __shfl_down(prims, off);
@@ -1070,6 +1092,7 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
     }
     if (lane == 0 && rays != 0u) {
         atomicAdd(&stats[7], (unsigned long long)rays);
+        if (coincident != 0u) atomicAdd(&stats[3], (unsigned long long)coincident);   // (word 3 is free on the device: the traversal time is the host's)
         if (P.count_tests) {
             atomicAdd(&stats[1], (unsigned long long)nodes);
             atomicAdd(&stats[2], (unsigned long long)prims);
@@ -1153,9 +1176,11 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ a
 
 __global__ void k_add_counters(unsigned long long* c, unsigned long long rays, unsigned long long boxes, unsigned long long prims,
                                unsigned long long traverse_ns, unsigned long long fetches, unsigned long long max_fetches,
-                               unsigned long long max_iters, const unsigned long long* __restrict__ shadow_rays) {
+                               unsigned long long max_iters, const unsigned long long* __restrict__ shadow_rays,
+                               const unsigned long long* __restrict__ coincident) {
     if (threadIdx.x == 0) {
         c[0] += rays + (shadow_rays ? *shadow_rays : 0ull);   // queue entries traversed (host count) + rays traced inside k_shadow
+        c[7] += coincident ? *coincident : 0ull;              // of which: counted as the reference counts them, traced as one (k_shadow)
         c[1] += boxes; c[2] += prims; c[3] += traverse_ns; c[4] += fetches;
         if (max_fetches > c[5]) c[5] = max_fetches;
         if (max_iters > c[6]) c[6] = max_iters;
@@ -1679,6 +1704,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (ws.levels_overflowed && ws.overflowed_scene != scene.serial) ws.levels_overflowed = false;   // another scene: try again
     if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;   // rays traced inside k_shadow
+    if ((e = hipMemsetAsync(ws.stats + 3, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;   // ... and those it counted without tracing
 
     if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
     const size_t first_event = ws.events_used;
@@ -1780,6 +1806,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             (void)hipEventRecord(ev0, stream);            // the accumulators are cleared before either stream adds to them
             (void)hipStreamWaitEvent(s2, ev0, 0);
             (void)hipMemsetAsync(w2.stats + 7, 0, sizeof(unsigned long long), s2);
+            (void)hipMemsetAsync(w2.stats + 3, 0, sizeof(unsigned long long), s2);
             int device = 0;
             (void)hipGetDevice(&device);
             std::atomic<bool> stop{false};
@@ -1813,6 +1840,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
         if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(ws.stats + 3, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
         ws.events_used = first_event;
         D.rays_traced = 0;
         partner_rays = 0;
@@ -1838,13 +1866,13 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         }
         ws.events_used = first_event;
         hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, ws.host_counts[0], ws.host_counts[1], ws.host_counts[2],
-                           (unsigned long long)(ms * 1e6), ws.host_counts[4], ws.host_counts[5], ws.host_counts[6], ws.stats + 7);
+                           (unsigned long long)(ms * 1e6), ws.host_counts[4], ws.host_counts[5], ws.host_counts[6], ws.stats + 7, ws.stats + 3);
     } else if (d_counters) {
         hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, D.rays_traced, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull,
-                           ws.stats + 7);
+                           ws.stats + 7, ws.stats + 3);
         if (partner_used)
             hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, stream, d_counters, partner_rays, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull,
-                               ws.partner->stats + 7);
+                               ws.partner->stats + 7, ws.partner->stats + 3);
     }
     return hipGetLastError();
 }

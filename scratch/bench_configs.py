@@ -56,7 +56,7 @@ def main():
         torch.cuda.synchronize(dev)
         wall = (time.perf_counter() - t0) * 1e3 / reps
         ms = e0.elapsed_time(e1) / reps
-        print(json.dumps({"config": label, "case": name, "resolution": [w, h], "spp": spp, "rays": int(st.rays),
+        print(json.dumps({"config": label, "case": name, "resolution": [w, h], "spp": spp, "rays": int(st.rays), "rays_traced": int(st.rays) - int(st.rays_coincident),
                           "kernel_ms": round(ms, 3), "traverse_ms": round(st.traverse_ms, 3), "wall_ms": round(wall, 3),
                           "Mrays_per_s": round(st.rays / ms / 1e3, 1), "mean_pixel": round(float(img.mean()), 2)}), flush=True)
         scene.close()

@@ -4,6 +4,8 @@
 Bar (BASELINE.json north_star): deterministic Whitted scenes, per-channel 8-bit max |diff| <= 1.
 The arithmetic is FP64 on both sides; libm differences (exp/log/atan2/...) and instruction-level rounding may move a
 value across a truncation boundary, hence <= 1 rather than == 0, and only on a small fraction of the channels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -110,3 +112,49 @@ def test_full_hd_frame_matches_the_reference(gpu):
         if ref_img is not None:
             mx, nd, _ = helpers.diff_stats(img, ref_img)
             assert mx <= TOL and nd <= MAX_OFF_FRACTION * img.size, (builder, mx, nd)
+
+
+def _mixed_lights_case():
+    """c1_shadows_fresnel (one light of radius 0.5) with a second light of radius 0 added."""
+    with open(os.path.join(helpers.GOLD, "configs", "c1_shadows_fresnel.json")) as f:
+        cfg = rt.Config(text=f.read())
+    kw, shutter = helpers.flags_to_kwargs(helpers.MANIFEST["c1_shadows_fresnel"]["flags"])
+    with open(os.path.join(helpers.GOLD, "scenes", "c1_shadows_fresnel.txt"), newline="") as f:
+        text = f.read()
+    text = ("POINT_LIGHT\n  location -3.0 -4.0 6.0\n  intensity 400.0 500.0 600.0\n  radius 0.0\nEND_POINT_LIGHT\n\n") + text
+    return rt.SceneFile(text=text, texture_root=os.path.join(helpers.GOLD, "scenes"), config=cfg, shutter_time=shutter), cfg, kw
+
+
+@pytest.mark.parametrize("rng", ["d0", "seeded"])
+def test_coincident_shadow_rays_are_traced_once_and_counted_as_the_reference_counts_them(gpu, rng, monkeypatch):
+    """The 2 x shadow_samples rays of a hit towards a light of radius 0 are one ray (shading.h:31-36): the wavefront schedule
+    traces it once with the summed weight.  Same frame and same `rays` as with RT_TRACE_COINCIDENT_RAYS=1, which traces every one
+    of them, and (deterministic sampling) as the megakernel, which always does; rays_coincident says how many were not traced.
+    Scenes: point lights only (one lane per bundle) and one light of each kind (the other lanes of a point light's bundle sit
+    out)."""
+    scene_file, params, golden = helpers.load_case("own_glass_env", rng=rng)
+    mixed, cfg, kw = _mixed_lights_case()
+    for desc, p in ((scene_file, params), (mixed, cfg.params(rng=rng, **kw))):
+        scene = rt.Scene(desc)
+        monkeypatch.delenv("RT_TRACE_COINCIDENT_RAYS", raising=False)
+        a, sa = scene.render(p, stats=True)
+        monkeypatch.setenv("RT_TRACE_COINCIDENT_RAYS", "1")
+        b, sb = scene.render(p, stats=True)
+        monkeypatch.delenv("RT_TRACE_COINCIDENT_RAYS", raising=False)
+        pm = p.copy()
+        pm.schedule = rt.RT_SCHEDULE_MEGAKERNEL
+        m, sm = scene.render(pm, stats=True)
+        scene.close()
+        assert int(sa.rays) == int(sb.rays)
+        assert int(sb.rays_coincident) == 0 and int(sm.rays_coincident) == 0 and 0 < int(sa.rays_coincident) < int(sa.rays)
+        # every coincident group is 2 x shadow_samples queries of which one is traced
+        assert int(sa.rays_coincident) % (2 * p.shadow_samples - 1) == 0
+        assert int(sb.prims_tested) > int(sa.prims_tested)
+        mx, nd, n1 = helpers.diff_stats(a, b)
+        assert mx <= 1 and nd <= 0.002 * a.size
+        if rng == "d0":
+            assert int(sa.rays) == int(sm.rays)
+            mx, nd, n1 = helpers.diff_stats(a, m)
+            assert mx <= 1 and nd <= 0.002 * a.size
+    if rng == "d0":
+        assert helpers.diff_stats(a, oracle_py.render(mixed, cfg.params(rng="d0", **kw)))[0] <= 1
