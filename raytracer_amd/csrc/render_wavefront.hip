@@ -1702,9 +1702,10 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     size_t max_queue_rays = ws.capacity;
     if (!ws.fixed && (e = prepare_workspace(scene, params, stream, ws, npix, may_emit, &max_queue_rays)) != hipSuccess) return e;
     if (ws.levels_overflowed && ws.overflowed_scene != scene.serial) ws.levels_overflowed = false;   // another scene: try again
-    if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;   // rays traced inside k_shadow
-    if ((e = hipMemsetAsync(ws.stats + 3, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;   // ... and those it counted without tracing
+    // the statistics words: all of them for a counting pass; else words 7 and 3 -- rays traced inside k_shadow, and those it counted
+    // without tracing (4 .. 6 lie between them and belong to the counting pass)
+    if ((e = params.count_tests ? hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)
+                                : hipMemsetAsync(ws.stats + 3, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
 
     if (ws.events_used + 64 > kMaxTimedEvents) ws.events_used = 0;   // nobody collected them (wavefront_traverse_time): start over
     const size_t first_event = ws.events_used;
@@ -1805,8 +1806,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             if ((e = hipEventCreateWithFlags(&ev1, hipEventDisableTiming)) != hipSuccess) { (void)hipEventDestroy(ev0); return e; }
             (void)hipEventRecord(ev0, stream);            // the accumulators are cleared before either stream adds to them
             (void)hipStreamWaitEvent(s2, ev0, 0);
-            (void)hipMemsetAsync(w2.stats + 7, 0, sizeof(unsigned long long), s2);
-            (void)hipMemsetAsync(w2.stats + 3, 0, sizeof(unsigned long long), s2);
+            (void)hipMemsetAsync(w2.stats + 3, 0, 5 * sizeof(unsigned long long), s2);
             int device = 0;
             (void)hipGetDevice(&device);
             std::atomic<bool> stop{false};
@@ -1838,9 +1838,8 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
         }
         if (!overflowed || D.err != hipSuccess) break;
         if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
-        if (params.count_tests && (e = hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(ws.stats + 7, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(ws.stats + 3, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        if ((e = params.count_tests ? hipMemsetAsync(ws.stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream)
+                                    : hipMemsetAsync(ws.stats + 3, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
         ws.events_used = first_event;
         D.rays_traced = 0;
         partner_rays = 0;
