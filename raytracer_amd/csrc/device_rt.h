@@ -31,8 +31,24 @@ __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 // vector3.h:92-102
+// The three quotients share their denominator.  The compiler expands an FP64 division into v_div_scale, v_rcp_f64, two Newton
+// steps on the reciprocal, q = x r, the remainder x - q len and one correction (v_div_fmas, v_div_fixup): correctly rounded, ~ 11
+// instructions and a quarter-rate reciprocal EACH.  Here the refined reciprocal is computed once and every component takes the
+// last three steps: the same operations on the same values -- hence the same bits -- whenever the scaling of v_div_scale is the
+// identity, which it is for a length in (1e-6, 1e150) and components no larger than it (RT_PLAIN_DIVISIONS: A/B runs).
 __device__ __forceinline__ D3 normalize(D3 a) {
     double len = length(a);
+#ifndef RT_PLAIN_DIVISIONS
+    if (len > 1e-6 && len < 1e150) {
+        double y = __builtin_amdgcn_rcp(len);
+        double e = fma(-len, y, 1.0);
+        y = fma(y, e, y);
+        e = fma(-len, y, 1.0);
+        y = fma(y, e, y);
+        double qx = a.x * y, qy = a.y * y, qz = a.z * y;
+        return D3{fma(fma(-len, qx, a.x), y, qx), fma(fma(-len, qy, a.y), y, qy), fma(fma(-len, qz, a.z), y, qz)};
+    }
+#endif
     if (len > 1e-6) return D3{a.x / len, a.y / len, a.z / len};
     return D3{0.0, 0.0, 0.0};
 }
