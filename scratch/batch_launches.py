@@ -11,6 +11,8 @@ rt.init(0)
 dev = torch.device("cuda", 0)
 scene = rt.Scene(workloads.bvh_stress_scene(1_000_000, 1920, 1080))
 p = workloads.default_config().params(rng="d0")
+if os.environ.get("RT_BATCH_SCHEDULE") == "fp32":   # the throughput variant
+    p.schedule = rt.RT_SCHEDULE_WAVEFRONT_FP32
 buf = torch.zeros((F, 1080, 1920, 3), dtype=torch.uint8, device=dev)
 st = torch.cuda.Stream(dev)
 torch.cuda.synchronize()
