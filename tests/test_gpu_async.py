@@ -239,6 +239,32 @@ def test_chunks_two_at_a_time_with_many_samples(gpu, monkeypatch):
         assert mx <= 1 and nd <= 0.01 * img.size
 
 
+@pytest.mark.parametrize("name", ["st_dof", "st_motion_blur"])
+def test_full_size_frames_in_chunk_pairs_equal_one_chunk_at_a_time(gpu, name, monkeypatch, tmp_path):
+    """BASELINE configs 3 (1080p, 64 spp) and 5 (3840x2160, 16 of its samples) at full size, where the chunks are 2^26 .. 2^27 rays:
+    two at a time and one at a time give the same ray count and the same frame up to the order of the FP64 additions."""
+    label, _, w, h, spp, rng = {c[1]: c for c in workloads.BASELINE_CONFIGS}[name]
+    scene_file, params = workloads.golden_scene(name, w, h, spp, rng, sky_dir=str(tmp_path))
+    dev = torch.device("cuda", 0)
+    scene = rt.Scene(scene_file)
+    out = {}
+    for mode in ("pairs", "one"):
+        if mode == "one":
+            monkeypatch.setenv("RT_ONE_CHUNK_AT_A_TIME", "1")
+        buf = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        counters = torch.zeros(8, dtype=torch.int64, device=dev)
+        stream = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        scene.render_device(params, buf.data_ptr(), d_counters_ptr=counters.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        out[mode] = (buf.cpu().numpy(), int(counters[0].item()))
+    scene.close()
+    rt.release_workspaces()
+    assert out["pairs"][1] == out["one"][1] > w * h * spp
+    mx, nd, _ = helpers.diff_stats(out["pairs"][0], out["one"][0])
+    assert mx <= 1 and nd <= 1e-4 * out["one"][0].size
+
+
 def test_render_on_torchs_default_stream_is_ordered_with_torch_work(gpu):
     """hip_stream NULL is HIP's null stream == torch's default stream: a torch op enqueued right after the render reads the
     finished frame without any synchronisation in between (the multi-GPU recipe of INTEGRATION.md relies on this)."""
