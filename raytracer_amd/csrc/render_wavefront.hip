@@ -1811,19 +1811,25 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             (void)hipGetDevice(&device);
             std::atomic<bool> stop{false};
             int result2 = 0;
-            std::thread odd([&]() {
-                if (hipSetDevice(device) != hipSuccess) { result2 = -1; stop = true; return; }
-                for (size_t i = 1; i < chunks.size() && !stop.load(); i += 2) {
-                    result2 = run_chunk(D2, chunks[i], true);
-                    if (result2 != 0) stop = true;
-                }
-            });
+            std::thread odd;
+            bool threaded = true;
+            try {
+                odd = std::thread([&]() {
+                    if (hipSetDevice(device) != hipSuccess) { result2 = -1; stop = true; return; }
+                    for (size_t i = 1; i < chunks.size() && !stop.load(); i += 2) {
+                        result2 = run_chunk(D2, chunks[i], true);
+                        if (result2 != 0) stop = true;
+                    }
+                });
+            } catch (...) {   // no thread to be had: this one renders every chunk (nothing may leave through the C ABI)
+                threaded = false;
+            }
             int result1 = 0;
-            for (size_t i = 0; i < chunks.size() && !stop.load(); i += 2) {
+            for (size_t i = 0; i < chunks.size() && !stop.load(); i += threaded ? 2 : 1) {
                 result1 = run_chunk(D, chunks[i], true);
                 if (result1 != 0) stop = true;
             }
-            odd.join();
+            if (threaded) odd.join();
             (void)hipEventRecord(ev1, s2);
             (void)hipStreamWaitEvent(stream, ev1, 0);      // whatever follows on the caller's stream sees both halves
             (void)hipEventDestroy(ev0);
