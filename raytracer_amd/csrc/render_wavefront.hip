@@ -103,6 +103,16 @@ struct HitQ {
     rt_q4* p;
     unsigned stride;
 };
+// Queue records (rays, hit records, shadow bundles) are written by one kernel and read once by a later one, gigabytes apart: their
+// loads and stores carry the streaming hint (nontemporal), so they do not displace the scene and the tails from the caches.
+// C1 + shadows 1.35 -> 1.30 ms, C3 129.6 -> 126.0, C4 4.02 -> 3.92, C5's share 84.3 -> 83.0, C2 +0.3 % (RT_TEMPORAL_QUEUES: A/B).
+#ifndef RT_TEMPORAL_QUEUES
+#define RT_Q_LD(ptr) __builtin_nontemporal_load(ptr)
+#define RT_Q_ST(ptr, val) __builtin_nontemporal_store(val, ptr)
+#else
+#define RT_Q_LD(ptr) (*(ptr))
+#define RT_Q_ST(ptr, val) (*(ptr) = (val))
+#endif
 union RayBits {
     RayStore r;
     rt_q4 v[kRayPieces];
@@ -129,7 +139,7 @@ union HitBits {
 __device__ __forceinline__ RayRec ray_load_full(const RayQ& q, unsigned i) {
     RayBits b;
 #pragma unroll
-    for (int k = 0; k < kRayPieces; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    for (int k = 0; k < kRayPieces; ++k) b.v[k] = RT_Q_LD(&q.p[(size_t)k * q.stride + i]);
     RayRec r;
     unpack_head(b.r, r);
     r.w[0] = b.r.w[0]; r.w[1] = b.r.w[1]; r.w[2] = b.r.w[2];
@@ -140,7 +150,7 @@ __device__ __forceinline__ RayRec ray_load_full(const RayQ& q, unsigned i) {
 __device__ __forceinline__ RayRec ray_load_head(const RayQ& q, unsigned i) {
     RayBits b;
 #pragma unroll
-    for (int k = 0; k < kRayHeadPieces; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    for (int k = 0; k < kRayHeadPieces; ++k) b.v[k] = RT_Q_LD(&q.p[(size_t)k * q.stride + i]);
     RayRec r;
     unpack_head(b.r, r);
     r.w[0] = r.w[1] = r.w[2] = 1.0;
@@ -153,19 +163,19 @@ __device__ __forceinline__ void ray_store(const RayQ q, unsigned i, const RayRec
     b.r.w[0] = r.w[0]; b.r.w[1] = r.w[1]; b.r.w[2] = r.w[2];
     b.r.pixel = r.pixel; b.r.depth = r.depth; b.r.pad = 0;
 #pragma unroll
-    for (int k = 0; k < kRayPieces; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
+    for (int k = 0; k < kRayPieces; ++k) RT_Q_ST(&q.p[(size_t)k * q.stride + i], b.v[k]);
 }
 __device__ __forceinline__ HitRec hit_load(const HitQ q, unsigned i) {
     HitBits b;
-    b.v[0] = q.p[i];
-    b.v[1] = q.p[(size_t)q.stride + i];
+    b.v[0] = RT_Q_LD(&q.p[i]);
+    b.v[1] = RT_Q_LD(&q.p[(size_t)q.stride + i]);
     return b.h;
 }
 __device__ __forceinline__ void hit_store(const HitQ q, unsigned i, const HitRec& h) {
     HitBits b;
     b.h = h;
-    q.p[i] = b.v[0];
-    q.p[(size_t)q.stride + i] = b.v[1];
+    RT_Q_ST(&q.p[i], b.v[0]);
+    RT_Q_ST(&q.p[(size_t)q.stride + i], b.v[1]);
 }
 
 // Shadow rays do not travel through the ray queues.  A radiance hit writes ONE bundle per light -- what its
@@ -195,14 +205,14 @@ union BundleBits {
 __device__ __forceinline__ Bundle bundle_load(const BundleQ q, unsigned i) {
     BundleBits b;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) b.v[k] = q.p[(size_t)k * q.stride + i];
+    for (int k = 0; k < 8; ++k) b.v[k] = RT_Q_LD(&q.p[(size_t)k * q.stride + i]);
     return b.b;
 }
 __device__ __forceinline__ void bundle_store(const BundleQ q, unsigned i, const Bundle& v) {
     BundleBits b;
     b.b = v;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) q.p[(size_t)k * q.stride + i] = b.v[k];
+    for (int k = 0; k < 8; ++k) RT_Q_ST(&q.p[(size_t)k * q.stride + i], b.v[k]);
 }
 
 
