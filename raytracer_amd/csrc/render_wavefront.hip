@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(const DScene S, const DParams
     b.r.time_kind = time;
     b.r.word = rng.next();
 #pragma unroll
-    for (int k = 0; k < kRayHeadPieces; ++k) out.p[(size_t)k * out.stride + (unsigned)i] = b.v[k];
+    for (int k = 0; k < kRayHeadPieces; ++k) RT_Q_ST(&out.p[(size_t)k * out.stride + (unsigned)i], b.v[k]);
 }
 
 // ------------------------------------------------------------------------------------------ k_traverse
