@@ -1314,10 +1314,10 @@ struct Driver {
     QIn dense(unsigned n, unsigned lo = 0, unsigned hi = 0xffffffffu) { return QIn{nullptr, n, 1u, (unsigned)ws.capacity, lo, std::min(hi, n)}; }
     QIn sharded(int level, unsigned lo = 0, unsigned hi = 0xffffffffu) { return QIn{tails(level), 0u, K, region(), lo, hi}; }
     // grid of a kernel that strides over `in`: by the count where the host knows it, else by the machine; a multiple of the shards
-    unsigned grid_for(const QIn& in, unsigned long long bound_lanes) {
+    unsigned grid_for(const QIn& in, unsigned long long bound_lanes, int per_cu = 0) {
         unsigned long long blocks = (bound_lanes + kBlock - 1) / kBlock;
         if (!in.counts) return (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(blocks, 0x7fffffffull));
-        blocks = std::min<unsigned long long>(blocks, (unsigned long long)ws.compute_units * (unsigned)grid_blocks_per_cu);
+        blocks = std::min<unsigned long long>(blocks, (unsigned long long)ws.compute_units * (unsigned)(per_cu > 0 ? per_cu : grid_blocks_per_cu));
         const unsigned k = in.shards;
         return (unsigned)std::max<unsigned long long>(k, (blocks + k - 1) / k * k);
     }
@@ -1363,6 +1363,10 @@ struct Driver {
     // the 64-spp frames 1-2 %; 4: the same or worse but for C1 + shadows; 2: 20-30 % slower.  RT_GRID_BLOCKS_PER_CU: A/B runs)
     const int grid_blocks_per_cu = getenv("RT_GRID_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("RT_GRID_BLOCKS_PER_CU"))) : 8;
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && small_env_ok; }
+    // (A/B runs) workgroups per CU of the grids of the shading kernel that queues rays -- 2 are resident at its 220 registers: 1-2 %
+    // faster than 8 on every config -- and of k_shadow (default: what is resident, see launch_shadow)
+    const int shade_grid_per_cu = getenv("RT_SHADE_GRID_PER_CU") ? atoi(getenv("RT_SHADE_GRID_PER_CU")) : 2;
+    const int shadow_grid_per_cu = getenv("RT_SHADOW_GRID_PER_CU") ? atoi(getenv("RT_SHADOW_GRID_PER_CU")) : 0;
     // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
     EmitCtx emit_ctx(int qo, int out_level) {
         return EmitCtx{qo >= 0 ? rays(qo) : RayQ{nullptr, 0u, 0u, chunk}, tails(out_level), ws.counters + 2, qo >= 0 ? region() : 0u, direct,
@@ -1373,7 +1377,11 @@ struct Driver {
         const EmitCtx E = emit_ctx(qo, out_level);
         const QIn in{bundle_tails(), 0u, K, region(), 0u, 0xffffffffu};
         const unsigned long long bound = std::min<unsigned long long>((unsigned long long)n * (unsigned)S.n_lights, ws.capacity) * 2ull * (unsigned)P.shadow_samples;
-        const unsigned blocks = grid_for(in, bound);
+        // The variants with the ray marcher or the texture paths hold two workgroups per CU (a workgroup is one wave per SIMD): a grid of
+        // exactly those -- more only queue up behind them and stage the scene again (C4 3.91 -> 3.55 ms).  The analytic variant holds four and keeps the 8 per CU of the other striding grids: 4 is 3 % faster on C1 + shadows
+        // and 2 % slower on C3 and on the 3900-quad scene.
+        constexpr int kResident = (F & (RT_FEAT_COMPLEX | RT_FEAT_ENV)) ? RT_SHADOW_COMPLEX_WAVES : (F & RT_FEAT_TEXTURE) ? RT_SHADOW_TEX_WAVES : 0;
+        const unsigned blocks = grid_for(in, bound, shadow_grid_per_cu > 0 ? shadow_grid_per_cu : kResident);
         if (small_scene())
             hipLaunchKernelGGL((k_shadow<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, E.bundles, in, E, accum, ws.stats);
         else
@@ -1389,7 +1397,7 @@ struct Driver {
     template <int F> void launch_shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
         const int level = out_level - 1;
         const EmitCtx E = emit_ctx(qo, out_level);
-        const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi)));
+        const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi), may_emit ? shade_grid_per_cu : 0));
         const QIn& v = in;
         if (may_emit && small_scene())
             hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
