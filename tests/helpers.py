@@ -99,3 +99,39 @@ def load_stochastic(name, spp, seed):
     scene, params, hi = load_case(name, rng="seeded", aa=spp, seed=seed)
     lo = np.load(os.path.join(GOLD, "images", name + ".npz"))["image_lo"]
     return scene, params, hi, lo, MANIFEST[name]["psnr_lo_vs_hi"]
+
+
+def bias_bars(name):
+    """Reference-internal noise figures of a stochastic case from its SIXTEEN independent 256-spp renders by the real
+    reference (`hi_stack`, oracle/gen_golden_r3.py).  -> (hi = stack[0], mean of the sixteen as float, floor, halves):
+      floor   PSNR of one 256-spp render against another, from the mean squared error over all 120 pairs (one pair alone
+              scatters by +-1 dB where only a few penumbra pixels carry the noise: soft shadows 51.9 ... 54.0 dB)
+      halves  PSNR of the mean of eight of the renders against the mean of the other eight."""
+    stack = np.load(os.path.join(GOLD, "images", name + ".npz"))["hi_stack"].astype(np.float64)
+    n = len(stack)
+    pair_mse = np.mean([np.mean((stack[i] - stack[j]) ** 2) for i in range(n) for j in range(i + 1, n)])
+    return stack[0].astype(np.uint8), stack.mean(axis=0), float(10.0 * np.log10(255.0 ** 2 / pair_mse)), psnr(stack[: n // 2].mean(axis=0), stack[n // 2:].mean(axis=0))
+
+
+def check_bias(img, name, label=""):
+    """Bar (1), the north-star bound at a sample count where it can see bias: a >= 1024-spp render `img` (uint8) must be no
+    further from the reference's 256-spp render than the reference's own second 256-spp render is (floor), minus 0.5 dB.
+    With 1024 samples the render's own noise is a quarter of the reference's 256-spp variance v, so noise alone leaves it
+    ~2 dB ABOVE the floor (mse 1.25 v against 2 v).  Returns the failure message or None."""
+    hi, _, floor, _ = bias_bars(name)
+    p_hi = psnr(img, hi)
+    print("bias %-16s %-18s PSNR vs ref_256 %.2f (floor %.2f)" % (name, label, p_hi, floor))
+    return None if p_hi >= floor - 0.5 else "%s: %.2f dB against the reference's 256-spp floor %.2f dB" % (name, p_hi, floor)
+
+
+def check_bias16(images, name, label=""):
+    """Bar (2), the sharp one.  `images`: sixteen independent 256-spp byte images of the device under test.  Their mean is
+    compared with the mean of the reference's sixteen: the same estimator on both sides (4096 samples per pixel, each render
+    truncated to bytes once, as the reference does), so truncation acts alike and the difference of the two means is noise
+    of 2 x (v / 4096 + truncation noise / 16) plus bias^2.  Two such means reach PSNR(mean of 8, mean of the other 8) + 3 dB
+    by noise alone; the bar is 1 dB below that.  A sampler parameter that is 10 % off fails it (tests/test_stochastic_cpu.py)."""
+    assert len(images) == 16
+    _, mean16, _, halves = bias_bars(name)
+    got = psnr(np.mean(np.stack(images).astype(np.float64), axis=0), mean16)
+    print("bias16 %-16s %-18s PSNR of the two means of 16: %.2f (noise alone %.2f, bar %.2f)" % (name, label, got, halves + 3.0, halves + 2.0))
+    return None if got >= halves + 2.0 else "%s: means of 16 x 256 spp differ: %.2f dB, noise alone gives %.2f dB" % (name, got, halves + 3.0)

@@ -90,5 +90,11 @@ def test_accumulation_stays_on_the_device(gpu):
     torch.cuda.synchronize()
     assert img.shape == (2160, 3840, 3)
     small = img.reshape(54, 40, 96, 40, 3).mean(axis=(1, 3))       # 96x54 box-filtered: the golden's size
-    assert helpers.psnr(small, hi) >= 30.0, helpers.psnr(small, hi)
+    # 64 spp x 1600 sub-pixels leave no noise of their own: what separates the box-filtered frame from the reference's 256-spp
+    # render is that render's noise (floor + 3 dB by noise alone; clamped highlights are averaged after clamping here).  Config
+    # 5 as specified (1024 spp) is held to the sharper bars of tests/test_gpu_stochastic.py::test_config5_as_specified_once.
+    floor = helpers.bias_bars("st_motion_blur")[2]
+    got = helpers.psnr(small, hi)
+    print("4K x 64 spp box-filtered bytes: %.2f dB (floor %.2f)" % (got, floor))
+    assert got >= floor + 1.0, (got, floor)
     big.close()

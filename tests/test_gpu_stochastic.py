@@ -1,6 +1,9 @@
 """GPU stochastic parity: seeded HIP renders (both schedules) of the distributed-effect scenes against the real
 reference's high-spp render.  Bar (north_star / BASELINE.md): PSNR(gpu N spp, reference hi spp) >=
 PSNR(reference N spp, reference hi spp) - 0.5 dB; and different seeds must give different, equally good images."""
+import os
+import re
+
 import numpy as np
 import pytest
 
@@ -24,6 +27,100 @@ def test_psnr_against_reference_high_spp(gpu, name, schedule):
     pa, pb = helpers.psnr(a, hi), helpers.psnr(b, hi)
     assert min(pa, pb) >= bar - 0.5, "%s: PSNR %.2f / %.2f dB vs reference's own %.2f dB" % (name, pa, pb, bar)
     assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("how", ["accumulate", "wavefront", "megakernel"])
+@pytest.mark.parametrize("name", helpers.STOCHASTIC)
+def test_bias_at_the_256_spp_noise_floor(gpu, name, how):
+    """A 16-spp PSNR is all variance and cannot see a biased sampler.  (1) The GPU renders 1024 spp, so that its own noise is
+    a quarter of the reference's 256-spp variance, and must stay within 0.5 dB of the reference's own 256-spp noise floor
+    (helpers.check_bias).  (2) Sixteen independent 256-spp GPU byte images are averaged and compared with the average of
+    the reference's sixteen (helpers.check_bias16: same estimator and truncation on both sides; bar 1 dB below what noise
+    alone gives).  tests/test_stochastic_cpu.py shows with the oracle that a light radius, aperture, shutter time or glossy
+    lobe that is 10 % off FAILS (2).  Both schedules; the wavefront schedule also through rt_accumulate_device (passes of 16
+    spp with seeds seed + k: the series config 5 is built from)."""
+    from raytracer_amd import progressive
+    scene_file, params, _, _, _ = helpers.load_stochastic(name, 16, seed=77)
+    scene = rt.Scene(scene_file)
+    params.schedule = rt.RT_SCHEDULE_MEGAKERNEL if how == "megakernel" else rt.RT_SCHEDULE_WAVEFRONT
+    images = []
+    for k in range(16):
+        p = params.copy()
+        p.seed = 77 + 100000 * (k + 1)
+        if how == "accumulate":
+            images.append(progressive.ProgressiveRender(scene, p).add_passes(16).image())
+        else:
+            p.samples_per_pixel = 256
+            images.append(scene.render(p))
+    if how == "accumulate":
+        big = progressive.ProgressiveRender(scene, params).add_passes(64).image()
+    else:
+        params.samples_per_pixel = 1024
+        big = scene.render(params)
+    scene.close()
+    failed = helpers.check_bias(big, name, how + " 1024 spp") or helpers.check_bias16(images, name, how)
+    assert failed is None, failed
+
+
+def _box_filtered(linear, fy, fx, tonemap):
+    from raytracer_amd import progressive
+    h, w, _ = linear.shape
+    small = linear.reshape(h // fy, fy, w // fx, fx, 3).mean(axis=(1, 3))
+    return progressive.to_image(small, tonemap)
+
+
+def _full_size_scene(name, width, height, spp, seed):
+    with open(os.path.join(helpers.GOLD, "scenes", name + ".txt"), newline="") as f:
+        text = re.sub(r"(?im)^(\s*resolution\s+)\d+\s+\d+", r"\g<1>%d %d" % (width, height), f.read())
+    with open(os.path.join(helpers.GOLD, "configs", name + ".json")) as f:
+        cfg = rt.Config(text=f.read())
+    kw, shutter = helpers.flags_to_kwargs(helpers.MANIFEST[name]["flags"])
+    sf = rt.SceneFile(text=text, texture_root=os.path.join(helpers.GOLD, "scenes"), config=cfg, shutter_time=shutter)
+    return sf, cfg.params(rng="seeded", aa=spp, seed=seed, **{k: v for k, v in kw.items() if k != "aa"})
+
+
+def test_config3_at_its_own_size_against_the_reference(gpu):
+    """BASELINE config 3 as specified: dof.txt at 1920x1080, 64 spp, soft shadows + glossy + depth of field, ONE call.  The
+    linear frame box-filtered 20x20 is the reference's estimator for the 96x54 frame (a pixel's footprint is the union of its
+    400 sub-pixels, main.cpp:291-296) with 25 600 samples per pixel, i.e. no noise of its own: what separates it from the
+    reference's renders is their noise and bias.  Bars: against one 256-spp render the floor PSNR(ref', ref) + 2 dB (noise
+    alone: mse v against 2 v, + 3 dB); against the mean of the sixteen PSNR(mean of 8, mean of other 8) + 2 dB (noise alone:
+    v / 16 against v / 4, + 6 dB, less what truncation costs: the sixteen were truncated to bytes one by one, which shifts a
+    noisy pixel by -0.5 level on average and a noise-free one by its fraction, this frame is truncated once -- measured + 3.7 dB
+    here and + 2.6 dB for config 5, the same to 0.05 dB for any seed since 25 600 samples leave no noise)."""
+    hi, mean16, floor, halves = helpers.bias_bars("st_dof")
+    sf, p = _full_size_scene("st_dof", 1920, 1080, 64, seed=5)
+    scene = rt.Scene(sf)
+    small = _box_filtered(scene.render_linear(p), 20, 20, int(p.tonemap))
+    scene.close()
+    p_hi, p_mean = helpers.psnr(small, hi), helpers.psnr(small, mean16)
+    print("C3 1080p x 64 spp box-filtered: PSNR vs ref_256 %.2f (floor %.2f), vs mean of 16 %.2f (halves %.2f)" % (p_hi, floor, p_mean, halves))
+    assert p_hi >= floor + 2.0 and p_mean >= halves + 2.0, (p_hi, floor, p_mean, halves)
+
+
+def test_config5_as_specified_once(gpu):
+    """BASELINE config 5 as specified, once: motion_blur.txt (floor textured with wood.jpg through the PIL path) at 3840x2160
+    x 1024 spp = 64 passes of 16 spp added up in HBM by rt_accumulate_device on one GPU.  Box-filtered 40x40 to the golden's
+    size and held to the same bars as config 3 -- an accumulation-order or seed-series bug over 64 passes (correlated
+    passes, a pass counted twice or dropped) shows as noise or bias at this level."""
+    import torch
+    from raytracer_amd import progressive
+    hi, mean16, floor, halves = helpers.bias_bars("st_motion_blur")
+    sf, p = _full_size_scene("st_motion_blur", 3840, 2160, 16, seed=2024)
+    scene = rt.Scene(sf)
+    run = progressive.ProgressiveRender(scene, p).add_passes(64)
+    torch.cuda.synchronize()
+    assert run.samples == 1024
+    lin = run.linear()
+    img = run.image()
+    scene.close()
+    assert img.shape == (2160, 3840, 3)
+    mx, nd, _ = helpers.diff_stats(img, progressive.to_image(lin, int(p.tonemap)))
+    assert mx <= 1 and nd <= 1e-3 * img.size
+    small = _box_filtered(lin, 40, 40, int(p.tonemap))
+    p_hi, p_mean = helpers.psnr(small, hi), helpers.psnr(small, mean16)
+    print("C5 4K x 1024 spp box-filtered: PSNR vs ref_256 %.2f (floor %.2f), vs mean of 16 %.2f (halves %.2f)" % (p_hi, floor, p_mean, halves))
+    assert p_hi >= floor + 2.0 and p_mean >= halves + 2.0, (p_hi, floor, p_mean, halves)
 
 
 def test_seeded_render_is_reproducible_per_pixel_sample(gpu):
