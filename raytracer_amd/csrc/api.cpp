@@ -294,7 +294,7 @@ static double max_camera_coordinate(const RtSceneDesc& desc) {
 // The hierarchy the device traverses, from the reference-topology tree that fixes the primitive order.
 static HostBvh traversal_tree(const RtSceneDesc& desc, const HostBvh& ref) {
     if (chosen_builder() == RT_BVH_MEDIAN) return ref;   // traverse the reference topology itself (A/B runs)
-    return build_traversal_bvh(permuted_boxes(ref.shape_boxes, ref.order), kMaxBinaryDepth);
+    return build_traversal_bvh(traversal_boxes(desc, ref.order), kMaxBinaryDepth);
 }
 static Bvh4 device_image(const RtSceneDesc& desc, const HostBvh& trav) {
     return to_node4(trav, max_camera_coordinate(desc));
@@ -400,7 +400,7 @@ int rt_bvh_device_image(const RtSceneDesc* desc, void* nodes_out, int32_t max_no
         if (!b4.nodes.empty()) std::memcpy(nodes_out, b4.nodes.data(), b4.nodes.size() * sizeof(DNode4));
     }
     if (prim_boxes_out) {
-        const std::vector<Box> boxes = permuted_boxes(ref.shape_boxes, ref.order);
+        const std::vector<Box> boxes = traversal_boxes(*desc, ref.order);   // what the hierarchy was built over
         for (int k = 0; k < desc->n_shapes; ++k) {
             store(prim_boxes_out + 6 * k, boxes[k].lo);
             store(prim_boxes_out + 6 * k + 3, boxes[k].hi);
@@ -449,11 +449,12 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     Bvh4 b32;
     sc->builder = chosen_builder(desc->n_shapes);
     if ((sc->builder == RT_BVH_LBVH || sc->builder == RT_BVH_SAH_GPU) && desc->n_shapes >= 2) {
-        const std::vector<Box> boxes = permuted_boxes(sc->bvh.shape_boxes, sc->bvh.order);
+        const std::vector<Box> boxes = traversal_boxes(*desc, sc->bvh.order);
+        const Box tight_root = union_of(boxes);
         clock.lap("primitive boxes");
         DeviceBvh4 dev4;
         hipError_t herr = hipSuccess;
-        const LbvhStatus st = build_lbvh_device(boxes, sc->bvh.root_box, max_camera_coordinate(*desc), g_dev.stream, &dev4, &herr,
+        const LbvhStatus st = build_lbvh_device(boxes, tight_root, max_camera_coordinate(*desc), g_dev.stream, &dev4, &herr,
                                                 sc->builder == RT_BVH_SAH_GPU);
         clock.lap("device hierarchy (with upload)");
         if (st == LbvhStatus::device_error) return fail(RT_ERR_DEVICE, std::string("device BVH build: ") + hipGetErrorString(herr));
@@ -466,7 +467,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
             for (int a = 0; a < 3; ++a) { b32.root_lo[a] = dev4.root_lo[a]; b32.root_hi[a] = dev4.root_hi[a]; }
             sc->n_nodes4 = dev4.n_nodes;
             sc->build_ms = dev4.build_ms;
-            sc->trav.root_box = sc->bvh.root_box;
+            sc->trav.root_box = tight_root;
             sc->trav.root_ref = 0;
         } else {
             sc->builder = RT_BVH_SAH;   // deeper than the traversal stack: the host builder bounds its depth
@@ -493,7 +494,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
         const double pad = b32.pad > 0.0 ? b32.pad : node4_pad(sc->bvh.root_box, max_camera_coordinate(*desc));
         prim_boxes.resize(static_cast<size_t>(desc->n_shapes) * 6);
         for (int k = 0; k < desc->n_shapes; ++k) {
-            const Box& b = sc->bvh.shape_boxes[sc->bvh.order[k]];
+            const Box b = traversal_bounds(desc->shapes[sc->bvh.order[k]], desc->shutter_time);
             for (int a = 0; a < 3; ++a) {
                 prim_boxes[6 * k + a] = round_down(b.lo[a] - pad);
                 prim_boxes[6 * k + 3 + a] = round_up(b.hi[a] + pad);

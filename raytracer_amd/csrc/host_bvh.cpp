@@ -122,6 +122,39 @@ Box shape_bounds(const RtShape& s, double shutter_time) {
     }
 }
 
+// What the TRAVERSAL hierarchy is built over.  The reference bounds a transformed sphere by the box of the eight transformed
+// corners of [-1, 1]^3 (transformed_shape.h:42-77) -- the box of the ORIENTED BOX around the ellipsoid, up to sqrt(3) too wide per
+// axis for a rotated one.  That box has to stay what the reference-order pass sees (its axis choices and centres decide the
+// visit order, which decides ties); the hierarchy the device traverses only culls, so any box that contains the surface
+// will do, and the ellipsoid {M p + c : |p| <= r} reaches exactly r * |row_i(M)|_2 along axis i.  A ray that misses this box
+// misses the ellipsoid, so the closest hit is unchanged.  The rows come from the forward matrix, as the reference's box does,
+// widened by 1e-9 of the extent (the surface itself is defined through the inverse matrix the tests use; the two agree to
+// ~1e-15 relative) -- five orders of magnitude below the outward pad of the node boxes (node4_pad).
+static Box ellipsoid_box(const RtShape& s, double r, double shutter_time) {
+    const M4 m = from_row_major(s.transform);
+    const bool affine = m.m[3][0] == 0.0 && m.m[3][1] == 0.0 && m.m[3][2] == 0.0 && m.m[3][3] == 1.0;
+    if (!affine) return transformed_box(s, V3(-r, -r, -r), V3(r, r, r), shutter_time);
+    Box b;
+    double c[3], h[3];
+    for (int i = 0; i < 3; ++i) {
+        c[i] = m.m[i][3];
+        h[i] = r * std::sqrt(m.m[i][0] * m.m[i][0] + m.m[i][1] * m.m[i][1] + m.m[i][2] * m.m[i][2]);
+        h[i] += 1e-9 * h[i] + 1e-300;
+        if (!std::isfinite(h[i])) return transformed_box(s, V3(-r, -r, -r), V3(r, r, r), shutter_time);
+    }
+    b.lo = V3(c[0] - h[0], c[1] - h[1], c[2] - h[2]);
+    b.hi = V3(c[0] + h[0], c[1] + h[1], c[2] + h[2]);
+    const V3 d = V3(s.velocity) * shutter_time;   // every position of the centre over the shutter interval (sphere.cpp:47)
+    return combine(b, Box{b.lo + d, b.hi + d});
+}
+
+Box traversal_bounds(const RtShape& s, double shutter_time) {
+    if (std::getenv("RT_REFERENCE_BOXES")) return shape_bounds(s, shutter_time);   // A/B runs: the reference's boxes everywhere
+    if (s.type == RT_SHAPE_SPHERE) return ellipsoid_box(s, 1.0, shutter_time);
+    if (s.type == RT_SHAPE_COMPLEX_SPHERE) return ellipsoid_box(s, 1.0 + s.max_displacement, shutter_time);   // complex_sphere.cpp:30-60: hits lie within |p| <= 1 + D
+    return shape_bounds(s, shutter_time);
+}
+
 namespace {
 
 struct Builder {
@@ -561,6 +594,16 @@ std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order) {
     std::vector<Box> boxes(n);
     parallel_for(n, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) boxes[i] = shape_bounds(desc.shapes[order ? order[i] : static_cast<int32_t>(i)], desc.shutter_time);
+    });
+    return boxes;
+}
+
+std::vector<Box> traversal_boxes(const RtSceneDesc& desc, const std::vector<int32_t>& order) {
+    std::vector<Box> boxes(order.size());
+    const bool reference = std::getenv("RT_REFERENCE_BOXES") != nullptr;
+    parallel_for(order.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i)
+            boxes[i] = reference ? shape_bounds(desc.shapes[order[i]], desc.shutter_time) : traversal_bounds(desc.shapes[order[i]], desc.shutter_time);
     });
     return boxes;
 }

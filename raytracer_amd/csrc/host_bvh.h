@@ -22,6 +22,12 @@ struct HostBvh {
 // World-space box of one shape at build time (transformed_shape.h:42-77, plane.cpp:11-46,
 // complex_sphere.cpp:21-27, complex_cube.cpp:25-31, complex_plane.cpp:24-75).
 Box shape_bounds(const RtShape& s, double shutter_time);
+// The box the TRAVERSAL hierarchy uses for a shape: the reference's box, except for (displaced) spheres, whose ellipsoid is
+// bounded exactly instead of through the corners of its oriented box.  Contained in shape_bounds() and containing the
+// surface: culling with it cannot change a hit.  RT_REFERENCE_BOXES=1 (environment) returns shape_bounds() for A/B runs.
+Box traversal_bounds(const RtShape& s, double shutter_time);
+// traversal_bounds of shape order[k] for every k (host threads): the boxes of the primitives in primitive order.
+std::vector<Box> traversal_boxes(const RtSceneDesc& desc, const std::vector<int32_t>& order);
 // The boxes of all shapes (host threads); box k belongs to shape order[k], or to shape k when order is NULL.
 std::vector<Box> shape_boxes(const RtSceneDesc& desc, const int32_t* order);
 // The union of all boxes (host threads); an empty list yields an inverted box.

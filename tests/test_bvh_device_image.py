@@ -133,3 +133,49 @@ def test_builds_do_not_depend_on_the_number_of_host_threads(clustered, monkeypat
         results.append((order.tobytes(), img["nodes"].tobytes(), img["root_ref"], img["info"].max_depth, info.n_nodes, info.max_depth))
     assert results[0] == results[1] == results[2]
     assert sorted(np.frombuffer(results[0][0], dtype=np.int32).tolist()) == list(range(70_000))
+
+
+def test_traversal_boxes_of_spheres_bound_the_ellipsoid_exactly(monkeypatch):
+    """The traversal hierarchy bounds a transformed sphere by its ellipsoid's own extent (host_bvh.cpp: traversal_bounds),
+    not by the reference's box of eight transformed cube corners (transformed_shape.h:42-77).  Per primitive: (a) every point
+    of the surface -- M p + c for unit vectors p, the matrix the reference's corner box uses -- lies inside the box, and the
+    extreme points touch it (so it is exact, not merely smaller); (b) the box lies inside the reference's box, which
+    RT_REFERENCE_BOXES=1 brings back; (c) for a moving sphere it covers both ends of the shutter interval."""
+    n = 300
+    rng = np.random.default_rng(3)
+    trs = np.zeros((n, 9))
+    trs[:, 0:3] = rng.uniform(-2, 2, (n, 3))
+    trs[:, 3:6] = rng.uniform(-3.2, 3.2, (n, 3))
+    trs[:, 6:9] = rng.uniform(0.01, 0.8, (n, 3))
+    shapes = rt.shapes_from_trs(trs)
+    shapes["velocity"][: n // 3] = rng.uniform(-1, 1, (n // 3, 3))
+    cam = rt.RtCamera()
+    cam.location[:] = [3, -3, 2]; cam.gaze_direction[:] = [-0.6, 0.6, -0.4]; cam.up_vector[:] = [0, 0, 1]
+    cam.focal_length, cam.sensor_width, cam.sensor_height = 50, 36, 24
+    cam.resolution_x, cam.resolution_y, cam.f_stop, cam.focal_distance = 64, 36, 99999.0, 10.0
+    shutter = 0.5
+    sb = rt.SceneBuilder(cam, [], shapes, [rt.default_material()], shutter_time=shutter)
+    _, order = rt.bvh_build_host(sb)
+    tight = rt.bvh_device_image(sb)["prim_boxes"]
+    monkeypatch.setenv("RT_REFERENCE_BOXES", "1")
+    loose = rt.bvh_device_image(sb)["prim_boxes"]
+    monkeypatch.delenv("RT_REFERENCE_BOXES")
+    _check_image(rt.bvh_device_image(sb), n)
+    p = rng.normal(size=(4000, 3))
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    shrink = []
+    for k in range(n):
+        s = shapes[order[k]]
+        m = np.array(s["transform"]).reshape(4, 4)
+        pts = p @ m[:3, :3].T + m[:3, 3]
+        moved = pts + np.array(s["velocity"]) * shutter
+        for q in (pts, moved):
+            assert np.all(q >= tight[k, 0:3] - 1e-12) and np.all(q <= tight[k, 3:6] + 1e-12)
+        assert np.all(tight[k, 0:3] >= loose[k, 0:3] - 1e-12) and np.all(tight[k, 3:6] <= loose[k, 3:6] + 1e-12)
+        # exact: the extreme point of the ellipsoid along +x, M M^T e_x / |M^T e_x|, touches the upper x plane (still sphere: no motion)
+        if not np.any(s["velocity"]):
+            row = m[0, :3]
+            ext = m[:3, :3] @ (row / np.linalg.norm(row)) + m[:3, 3]
+            assert abs(ext[0] - tight[k, 3]) <= 1e-8 * max(1.0, abs(ext[0]))
+        shrink.append(np.prod(tight[k, 3:6] - tight[k, 0:3]) / np.prod(loose[k, 3:6] - loose[k, 0:3]))
+    assert np.mean(shrink) < 0.7   # rotated ellipsoids: the boxes hold well under the volume of the corner boxes
