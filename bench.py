@@ -284,6 +284,12 @@ def main():
     # the next launch.  This one thread issues everything in step order on every rank.
     # --frames-in-flight F selects the round-1 setting instead: one frame per call on F streams.
     B = max(1, args.frames_per_launch) if args.frames_per_launch else min(64, 16 * world)
+    B_steady = B
+    # never more frames per launch than the timed region has (a set would ship empty slots), and with several GPUs at least two
+    # batches, so that one batch's exchange overlaps the other's render
+    B = min(B, max(1, args.steps))
+    if world > 1 and args.steps >= 2:
+        B = min(B, (args.steps + 1) // 2)
     S, n_streams = max(1, args.sets), 1
     if args.frames_in_flight is not None:
         B, S = 1, max(1, args.frames_in_flight)
@@ -291,7 +297,7 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     counters = torch.zeros(8, dtype=torch.int64, device=dev)   # RT_N_COUNTERS
     sets = [FrameGather(W, H, args.tile_rows, dev, frames=B, native=native_exchange) for _ in range(S)]   # slices [B, max_rows, W, 3]; frames on rank 0
-    batch_events = []
+    batch_events, gather_events = [], []
 
     # All exchanges are issued on ONE stream of their own, in batch order (operations of a communicator stay ordered whatever
     # the RCCL version makes of several user streams), tied to the render streams by events both ways: the exchange of a set
@@ -321,7 +327,12 @@ def main():
         if world > 1:
             with torch.cuda.stream(gather_stream):
                 gather_stream.wait_event(rendered)
-                fg.run()   # RCCL send/recv of the set's slices to rank 0 + k_deinterleave
+                if timed:
+                    gather_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                    gather_events[-1][0].record(gather_stream)
+                fg.run(1 if (collect or B == 1) else (nb or B))   # RCCL send/recv of the batch's slices to rank 0 + k_deinterleave: a partial batch ships its own bytes
+                if timed:
+                    gather_events[-1][1].record(gather_stream)
                 done[k % S] = torch.cuda.Event()
                 done[k % S].record(gather_stream)
 
@@ -353,6 +364,7 @@ def main():
     for st in streams:
         scene.traverse_time(st.cuda_stream)   # drop the warm-up launches from the kernel timing
     if world > 1:
+        rt.gather_time()                      # ... and the warm-up gathers from the exchange timing
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -369,6 +381,54 @@ def main():
         elapsed = float(tmax.item())
     # time from the first kernel of a frame's batch to its last (the frame is complete when its batch is)
     render_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in batch_events])) if batch_events else 0.0
+    # Where the timed region went, per rank: device time of the renders, of the gathers (as the gather stream saw them: waiting for
+    # the other ranks' slices included) and, inside the library's own exchange, of its two halves (rt_gather_time: grouped
+    # ncclSend / ncclRecv, then k_deinterleave on rank 0).  The line carries the maximum over the ranks and rank 0's own figures:
+    # rank 0 is receiver, de-interleaver and a full renderer at once, so an imbalance shows here and not as a slow render.
+    phases = None
+    if world > 1:
+        mine = [sum(a.elapsed_time(b) for a, b, _ in batch_events), sum(a.elapsed_time(b) for a, b in gather_events), 0.0, 0.0]
+        if native_exchange:
+            ex_ms, de_ms, _n = rt.gather_time()
+            mine[2], mine[3] = ex_ms, de_ms
+        t = torch.tensor(mine, dtype=torch.float64, device=dev)
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        t0_ = t.clone()
+        dist.broadcast(t0_, src=0)
+        keys = ["render_ms", "gather_ms", "exchange_ms", "deinterleave_ms"]
+        phases = {"max_over_ranks": {k: round(float(v), 4) for k, v in zip(keys, tm.cpu().tolist())},
+                  "rank0": {k: round(float(v), 4) for k, v in zip(keys, t0_.cpu().tolist())},
+                  "timed_region_ms": round(elapsed * 1e3, 4), "batches": len(batch_events),
+                  "bytes_per_exchange_per_rank": [int(nb * sets[0].max_rows * W * 3) for _, _, nb in batch_events],
+                  "note": "device time summed over the timed region's batches; render and gather run on streams of their own and overlap"}
+    # The driver's --steps is small against a launch (20 frames over 8 GPUs are 2.5 frames of rays per rank and launch: one tail of
+    # the persistent traversal kernel per launch, and an exchange with nothing left to hide behind): the same job over a region
+    # long enough to fill the launches, for diagnosis -- NOT the value of this line.
+    steady = None
+    if world > 1 and args.frames_in_flight is None and B_steady > B:
+        big = [FrameGather(W, H, args.tile_rows, dev, frames=B_steady, native=native_exchange) for _ in range(S)]
+        saved = (sets, B)
+        sets, B = big, B_steady
+        done[:] = [None] * S
+        run(B_steady * S)                     # warm-up: every set once
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        n_steady = 4 * B_steady
+        run(n_steady)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        tmax2 = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax2, op=dist.ReduceOp.MAX)
+        steady = {"steps": n_steady, "frames_per_launch": B_steady, "ms_per_step": round(float(tmax2.item()) * 1e3 / n_steady, 4),
+                  "Mrays_per_s": round(rays_frame * n_steady / float(tmax2.item()) / 1e6, 1),
+                  "note": "same job, same barriers, %d steps in launches of %d frames: what the partition sustains; not this line's value" % (n_steady, B_steady)}
+        sets, B = saved
+        done[:] = [None] * S
+        del big
     # device time of the k_traverse launches of the timed region (hipEvents recorded by the library on the launch streams):
     # launches in flight on several streams overlap and share the GPU, so each one lasts longer than it would alone
     tt = [scene.traverse_time(st.cuda_stream) for st in streams]
@@ -525,6 +585,7 @@ def main():
                        "gathered_frame_equals_whole_frame": frame_ok},
             "ms_per_frame": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(t_enqueued * 1e3 / max(1, args.steps), 4),
             "frame_latency_ms_in_flight": round(render_ms, 4),
+            "phases": phases, "steady_state": steady,
             "ms_per_frame_solo": round(solo_ms, 4) if solo_ms else None,
             "Mrays_per_s_solo": round(rays_frame / solo_ms / 1e3, 1) if solo_ms else None,
             "ms_per_frame_host_buffer": round(host_ms, 4) if host_ms else None,

@@ -309,16 +309,24 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
 int rt_render_frames_device(rt_scene_t scene, const RtRenderParams* params, int frames, int slice_rows, void* d_rgb8,
                             void* d_counters, void* hip_stream);
 
-/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has NO counterpart in the reference (which has no device): same pixels as
- * rt_render_device with the wavefront schedule, but every buffer the kernels need beyond the scene and d_rgb8 -- ray
- * queues, hit records, FP64 accumulators, queue counters -- lies in a 64 MiB __device__ array inside the library (one
- * copy per GPU, held until the process ends), and the call allocates and frees nothing on the device.
+/* rt_render_device for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc,
+ * code under HIP graph capture -- for the frames named below).  It has NO counterpart in the reference (which has no
+ * device): same pixels as rt_render_device with the wavefront schedule, but every buffer the kernels need beyond the scene
+ * and d_rgb8 -- ray queues, hit records, FP64 accumulators, queue counters -- lies in a 64 MiB __device__ array inside the
+ * library (one copy per GPU, held until the process ends), and the call allocates and frees nothing on the device (the
+ * pinned host words of its read-backs are allocated by rt_init).
+ * What the call does on the stream: a frame that cannot queue a ray (no material reflects or transmits and shadows are off,
+ * or --normals: BASELINE config 2) is enqueued and the call returns at once, like rt_render_device -- nothing is read back,
+ * so such a call is legal under stream capture.  A frame that CAN queue rays is cut into chunks, and after every chunk the
+ * host reads 24 bytes back (queue overflow flag, rays still queued, ray total) and WAITS for the stream
+ * (hipMemcpyAsync + hipStreamSynchronize, illegal during capture): the call blocks until all but the last kernels of the frame
+ * have run.  Do not call it under capture for such frames.
  * Limits (RT_ERR_LIMIT with a message): the rendered part (rt_part_rows x width) holds at most 2^18 pixels and is at most
- * 1024 pixels wide -- larger frames are rendered in parts -- and the frame's ray tree must fit the queues that fit the
- * array (one queue per ray-tree level; chains of shadow segments through many transmitting surfaces may not).
+ * 1024 pixels wide -- larger frames are rendered in parts -- an 8-row band of the part must fit one of the queues that fit the
+ * array, and so must the frame's ray tree (one queue per ray-tree level; chains of shadow segments through many transmitting
+ * surfaces may not).
  * All calls on a GPU share the array: calls that overlap on one GPU (different streams or threads) race; run them one
- * after the other.  Returns when the last level has been enqueued on `hip_stream`, like rt_render_device. */
+ * after the other. */
 int rt_render_device_noalloc(rt_scene_t scene, const RtRenderParams* params, void* d_rgb8, void* hip_stream);
 
 /* Ray queues of the wavefront schedule are kept per HIP stream for the life of the process, not per scene: a service that
@@ -353,9 +361,12 @@ int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void
 int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d_sum_f64, uint64_t first_pass, int passes, void* hip_stream);
 int rt_resolve_sum_device(const void* d_sum_f64, uint64_t passes, int width, int rows, int tonemap, void* d_rgb8, void* hip_stream);
 
-/* Device time (hipEvents on the launch stream) of the BVH-traversal kernel launches that rt_render_device enqueued on
- * `hip_stream` for this scene since the last call of this function, and how many launches that was.  The stream must
- * have been synchronised by the caller (RT_ERR_DEVICE otherwise).  No counterpart in the reference: it feeds the
+/* Device time (hipEvents on the launch stream) of the BVH-traversal kernel launches that the render entry points enqueued on
+ * `hip_stream` since the last call of this function, and how many launches that was -- of EVERY scene rendered on that
+ * stream: the ray queues and their event lists belong to the stream, not to the scene (rt_reserve), so `scene` only has to be
+ * a valid handle; render one scene per stream between two calls to time that scene.  The stream must have been
+ * synchronised by the caller (RT_ERR_DEVICE otherwise).  hip_stream == NULL means the NULL stream here and in every
+ * *_device entry point (HIP's own meaning; round 1 used a stream of the library's own for NULL).  No counterpart in the reference: it feeds the
  * roofline figure of bench.py (the reference only has wall-clock timing, main.cpp:271,350-358). */
 int rt_traverse_time(rt_scene_t scene, void* hip_stream, double* ms_out, uint64_t* launches_out);
 
@@ -387,8 +398,18 @@ int rt_comm_destroy(void);
  * of each slot unused) -- several frames travel in one message, because a rank's share of one frame is small (0.78 MB of
  * a 1080p frame at 8 ranks) and the exchange is bound by its launch cost.  d_frames (rank 0 only, else ignored):
  * frames x height x width x 3 bytes, row-major, top row first.  Without a communicator (one GPU) it only reorders.
- * Rank 0 keeps a staging buffer of world x frames x max_rows x width x 3 bytes, grown on demand, until rt_comm_destroy. */
+ * Rank 0 keeps a staging buffer of world x frames x max_rows x width x 3 bytes PER STREAM it has gathered on, grown on demand
+ * (growing waits for the whole device once) and kept until rt_comm_destroy: gathers on different streams may be in flight
+ * together; RCCL orders the messages of the one communicator.  The call holds the library's communicator lock while it
+ * enqueues, so it may be called from several threads.  An RCCL error inside the grouped send / receive closes the group
+ * before it is reported.  A partial batch passes its own `frames`: the message is frames x max_rows x width x 3 bytes. */
 int rt_gather_frames(const void* d_slices, int frames, int width, int height, int tile_rows, void* d_frames, void* hip_stream);
+/* Device time of the gathers since the last call of this function, summed: `exchange` = the grouped ncclSend / ncclRecv of a
+ * gather, `deinterleave` = its k_deinterleave launch (rank 0; zero elsewhere), from HIP events the library records on the
+ * gather's stream, and how many gathers that was (at most the last 512).  The streams must have been synchronised by the
+ * caller (RT_ERR_DEVICE otherwise).  It tells a slow exchange from a slow render on rank 0, which is receiver, de-interleaver
+ * and a full renderer at once.  No counterpart in the reference (shared memory, main.cpp:242). */
+int rt_gather_time(double* exchange_ms_out, double* deinterleave_ms_out, uint64_t* gathers_out);
 /* rt_render for an N-GPU job -- the drop-in for the body of render_scene_func (main.cpp:229-359) when the frame is shared
  * by several GPUs.  Collective: every rank calls it with the same scene and params (part_index / part_count are set from
  * the communicator); each rank renders its tiles, the slices are gathered, and rank 0 gets the whole frame in rgb8_out

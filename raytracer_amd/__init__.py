@@ -121,6 +121,7 @@ ABI_SYMBOLS = [
     "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_render_device_noalloc", "rt_render_frames_device", "rt_reserve",
     "rt_release_workspaces", "rt_comm_unique_id", "rt_comm_init", "rt_comm_rank", "rt_comm_world", "rt_comm_destroy",
     "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered", "rt_accumulate_device", "rt_resolve_sum_device",
+    "rt_gather_time",
 ]
 
 
@@ -174,6 +175,7 @@ def _load():
         "rt_comm_unique_id": (i32, [vp]), "rt_comm_init": (i32, [i32, i32, vp]), "rt_comm_rank": (i32, []),
         "rt_comm_world": (i32, []), "rt_comm_destroy": (i32, []),
         "rt_gather_frames": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+        "rt_gather_time": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "rt_render_gathered": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_accumulate_device": (i32, [vp, C.POINTER(RtRenderParams), vp, C.c_uint64, i32, vp]),
         "rt_resolve_sum_device": (i32, [vp, C.c_uint64, i32, i32, i32, vp, vp]),
@@ -260,6 +262,13 @@ def comm_destroy():
 def gather_frames(d_slices_ptr, frames, width, height, tile_rows, d_frames_ptr, stream=None):
     """Collective: slices of `frames` frames to rank 0 over RCCL + de-interleave kernel (see rt_gather_frames)."""
     _check(lib.rt_gather_frames(d_slices_ptr, int(frames), int(width), int(height), int(tile_rows), d_frames_ptr, stream))
+
+
+def gather_time():
+    """(exchange ms, de-interleave ms, gathers) of the gathers since the last call (their streams synchronised): rt_gather_time."""
+    ex, de, n = C.c_double(0.0), C.c_double(0.0), C.c_uint64(0)
+    _check(lib.rt_gather_time(C.byref(ex), C.byref(de), C.byref(n)))
+    return ex.value, de.value, n.value
 
 
 def deinterleave_device(d_own_ptr, d_gathered_ptr, d_frames_ptr, frames, width, height, tile_rows, world, stream=None):

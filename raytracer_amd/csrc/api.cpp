@@ -702,6 +702,13 @@ static int make_dparams(rt_scene_t scene, const RtRenderParams* p, int collect, 
     return RT_OK;
 }
 
+// The device scene as the kernels get it (passed by value).  ensure_xforms32 may write scene->d.xforms32 while another thread
+// renders the same scene on another stream, so every render entry point takes its copy under the lock that write holds.
+static DScene scene_snapshot(rt_scene_t scene) {
+    std::lock_guard<std::mutex> lock(g_wf_mutex);
+    return scene->d;
+}
+
 // RT_SCHEDULE_WAVEFRONT_FP32 on a spheres-only scene: the FP32 copy of the transforms, made on the device by the first such
 // frame (on its stream, ahead of its kernels; later frames on other streams wait for it once) and kept with the scene.
 static int ensure_xforms32(rt_scene_t scene, const DParams& dp, hipStream_t st) {
@@ -735,10 +742,11 @@ int rt_render_device(rt_scene_t scene, const RtRenderParams* params, void* d_rgb
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if ((rc = ensure_xforms32(scene, dp, st))) return rc;
     hipError_t e;
+    const DScene ds = scene_snapshot(scene);
     if (params->schedule == RT_SCHEDULE_MEGAKERNEL)
-        e = launch_render_mega(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
+        e = launch_render_mega(ds, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st);
     else
-        e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
+        e = launch_render_wavefront(ds, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
                                     *workspace_of(st, true));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
@@ -766,7 +774,7 @@ int rt_render_frames_device(rt_scene_t scene, const RtRenderParams* params, int 
     dp.slice_rows = slice_rows;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if ((rc = ensure_xforms32(scene, dp, st))) return rc;
-    hipError_t e = launch_render_wavefront(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
+    hipError_t e = launch_render_wavefront(scene_snapshot(scene), dp, static_cast<uint8_t*>(d_rgb8), static_cast<unsigned long long*>(d_counters), st,
                                            *workspace_of(st, true));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
@@ -786,10 +794,13 @@ int rt_render_device_noalloc(rt_scene_t scene, const RtRenderParams* params, voi
         return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the part has " + std::to_string(npix) + " pixels, " + std::to_string(dp.width) +
                                       " wide; the static workspace holds parts of at most " + std::to_string(kStaticMaxPixels) + " pixels, at most " +
                                       std::to_string(kStaticMaxWidth) + " wide (render the frame in parts, or use rt_render_device)");
-    hipError_t e = launch_render_wavefront_static(scene->d, dp, static_cast<uint8_t*>(d_rgb8), static_cast<hipStream_t>(hip_stream), g_dev.device);
+    hipError_t e = launch_render_wavefront_static(scene_snapshot(scene), dp, static_cast<uint8_t*>(d_rgb8), static_cast<hipStream_t>(hip_stream), g_dev.device);
     if (e == hipErrorOutOfMemory)
         return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the ray tree of this frame needs more queues than the static workspace (" +
                                       std::to_string(kStaticScratchBytes >> 20) + " MiB) holds; use rt_render_device");
+    if (e == hipErrorInvalidValue)   // launch_render_wavefront_static / launch_render_wavefront: a band of 8 rows x width does not fit a queue
+        return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: an 8-row band of this part (" + std::to_string(dp.width) + " pixels wide, " +
+                                      std::to_string(dp.spp) + " samples) does not fit a ray queue of the static workspace; render narrower parts or use rt_render_device");
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }
@@ -804,7 +815,7 @@ int rt_render_linear_device(rt_scene_t scene, const RtRenderParams* params, void
     if (!scene->on_device) return fail(RT_ERR_DEVICE, "scene is not resident on the device");
     if (dp.part_rows == 0) return RT_OK;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipError_t e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, *workspace_of(st, true), static_cast<double*>(d_rgb_f64));
+    hipError_t e = launch_render_wavefront(scene_snapshot(scene), dp, nullptr, nullptr, st, *workspace_of(st, true), static_cast<double*>(d_rgb_f64));
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
     return RT_OK;
 }
@@ -832,11 +843,18 @@ int rt_accumulate_device(rt_scene_t scene, const RtRenderParams* params, void* d
     // is what running two PASSES at a time did before (4K x 16 spp with two area lights: 92 -> 82 ms per pass either way; two
     // passes at a time on top of chunk pairs would hold four sets of queues).
     hipError_t e = hipSuccess;
-    for (int k = 0; k < passes && e == hipSuccess; ++k) {
-        dp.seed = params->seed + first_pass + static_cast<uint64_t>(k);
-        e = launch_render_wavefront(scene->d, dp, nullptr, nullptr, st, ws, d_sum, 1);
+    const DScene ds = scene_snapshot(scene);
+    int done = 0;
+    for (; done < passes; ++done) {
+        dp.seed = params->seed + first_pass + static_cast<uint64_t>(done);
+        e = launch_render_wavefront(ds, dp, nullptr, nullptr, st, ws, d_sum, 1);
+        if (e != hipSuccess) break;
     }
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render kernel launch: ") + hipGetErrorString(e));
+    // A pass is added to the sum by its last kernel, after its render has succeeded: the sum holds exactly the passes counted here.
+    if (e != hipSuccess)
+        return fail(RT_ERR_DEVICE, "rt_accumulate_device: pass " + std::to_string(done) + " of " + std::to_string(passes) + " failed (" + hipGetErrorString(e) +
+                                       "); d_sum_f64 holds the " + std::to_string(done) + " passes before it (series positions " + std::to_string(first_pass) +
+                                       " .. " + std::to_string(first_pass + static_cast<uint64_t>(done)) + " exclusive)");
     return RT_OK;
 }
 

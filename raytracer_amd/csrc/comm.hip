@@ -16,8 +16,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/rt_mi355x.h"
 #include "api_internal.h"
@@ -40,14 +42,28 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_comm_mutex;
 
+// Rank 0 receives into a staging buffer [world][frames][max_rows][W*3] that k_deinterleave then reads.  One buffer PER
+// STREAM the caller gathers on: gathers on different streams may be in flight together (operations of one communicator are
+// ordered by RCCL, the buffers are not), and a buffer is only ever freed after the whole device has gone idle.
+struct Staging {
+    unsigned char* p = nullptr;
+    size_t bytes = 0;
+};
+// HIP events around the two halves of a gather on the caller's stream (rt_gather_time): start, after the RCCL group, after
+// k_deinterleave.  A fixed pool that wraps around: timings nobody collects are overwritten.
+struct GatherEvents {
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+};
+constexpr size_t kMaxGatherEvents = 512;
 struct CommState {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    unsigned char* staging = nullptr;   // rank 0: [world][frames][max_rows][W*3] as received
-    size_t staging_bytes = 0;
+    std::map<hipStream_t, Staging> staging;
+    std::vector<GatherEvents> events;
+    size_t events_used = 0;
     bool loopback = false;              // RT_COMM_LOOPBACK=1: rank 0 also sends its own slices to itself through RCCL (one-GPU tests)
 };
-CommState g_comm;
+CommState g_comm;   // every field is read and written under g_comm_mutex
 
 int load_rccl() {
     if (g_rccl.handle) return RT_OK;
@@ -168,16 +184,26 @@ int rt_comm_init(int rank, int world, const void* id) {
     return RT_OK;
 }
 
-int rt_comm_rank(void) { return g_comm.comm ? g_comm.rank : 0; }
-int rt_comm_world(void) { return g_comm.comm ? g_comm.world : 1; }
+int rt_comm_rank(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    return g_comm.comm ? g_comm.rank : 0;
+}
+int rt_comm_world(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    return g_comm.comm ? g_comm.world : 1;
+}
 
 int rt_comm_destroy(void) {
     std::lock_guard<std::mutex> lock(g_comm_mutex);
-    if (!g_comm.comm) return RT_OK;
+    if (!g_comm.comm && g_comm.staging.empty() && g_comm.events.empty()) return RT_OK;
     (void)hipSetDevice(rt::api_device());
     (void)hipDeviceSynchronize();
-    ncclResult_t r = g_rccl.comm_destroy(g_comm.comm);
-    if (g_comm.staging) (void)hipFree(g_comm.staging);
+    ncclResult_t r = g_comm.comm ? g_rccl.comm_destroy(g_comm.comm) : ncclSuccess;
+    for (auto& kv : g_comm.staging)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (GatherEvents& g : g_comm.events)
+        for (hipEvent_t e : g.e)
+            if (e) (void)hipEventDestroy(e);
     g_comm = CommState();
     if (r != ncclSuccess) return api_fail(RT_ERR_DEVICE, std::string("ncclCommDestroy: ") + g_rccl.error_string(r));
     return RT_OK;
@@ -204,33 +230,89 @@ int rt_deinterleave_device(const void* d_own, const void* d_gathered, void* d_fr
 int rt_gather_frames(const void* d_slices, int frames, int width, int height, int tile_rows, void* d_frames, void* hip_stream) {
     if (!rt::api_ready()) return api_fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
     if (!d_slices || frames < 1 || width <= 0 || height <= 0 || tile_rows <= 0) return api_fail(RT_ERR_INVALID, "rt_gather_frames: bad argument");
+    // The communicator and this stream's staging buffer are looked up -- and the RCCL calls issued -- under the mutex:
+    // rt_comm_destroy cannot pull either away in between, and two threads cannot interleave their groups.
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
     const int world = g_comm.comm ? g_comm.world : 1, rank = g_comm.comm ? g_comm.rank : 0;
     if (rank == 0 && !d_frames) return api_fail(RT_ERR_INVALID, "rt_gather_frames: rank 0 needs d_frames");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int max_rows = max_part_rows(height, tile_rows, world);
     const size_t frame_stride = (size_t)max_rows * width * 3, count = (size_t)frames * frame_stride;
     const bool self = g_comm.comm && g_comm.loopback;
+    // timing events of this gather (best effort: without them the gather still runs)
+    GatherEvents* ev = nullptr;
+    if (world > 1 || self) {
+        if (g_comm.events.size() < kMaxGatherEvents && g_comm.events_used == g_comm.events.size()) {
+            GatherEvents g;
+            bool ok = true;
+            for (hipEvent_t& e : g.e) ok = ok && hipEventCreate(&e) == hipSuccess;
+            if (ok) g_comm.events.push_back(g);
+            else for (hipEvent_t e : g.e) if (e) (void)hipEventDestroy(e);
+        }
+        if (!g_comm.events.empty()) {
+            ev = &g_comm.events[g_comm.events_used % g_comm.events.size()];
+            ++g_comm.events_used;
+            (void)hipEventRecord(ev->e[0], st);
+        }
+    }
     if (rank != 0) {
         NCCL_TRY(g_rccl.send(d_slices, count, ncclUint8, 0, g_comm.comm, st));
+        if (ev) { (void)hipEventRecord(ev->e[1], st); (void)hipEventRecord(ev->e[2], st); }
         return RT_OK;
     }
+    unsigned char* staging = nullptr;
     if (world > 1 || self) {
         HIP_TRY(hipSetDevice(rt::api_device()));
         const size_t need = (size_t)world * count;
-        if (g_comm.staging_bytes < need) {   // grows with the first gather of a larger frame or batch; kept until rt_comm_destroy
-            HIP_TRY(hipStreamSynchronize(st));
-            if (g_comm.staging) (void)hipFree(g_comm.staging);
-            g_comm.staging = nullptr;
-            g_comm.staging_bytes = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_comm.staging), need));
-            g_comm.staging_bytes = need;
+        Staging& sg = g_comm.staging[st];
+        if (sg.bytes < need) {
+            // Grows with the first gather of a larger frame or batch on this stream; kept until rt_comm_destroy.  The old buffer
+            // may still be read by a de-interleave kernel of this stream, and hipFree of memory in use is undefined: the whole
+            // device goes idle first (once per size, not per gather).
+            HIP_TRY(hipDeviceSynchronize());
+            if (sg.p) (void)hipFree(sg.p);
+            sg = Staging();
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sg.p), need));
+            sg.bytes = need;
         }
-        NCCL_TRY(g_rccl.group_start());
-        if (self) NCCL_TRY(g_rccl.send(d_slices, count, ncclUint8, 0, g_comm.comm, st));
-        for (int k = self ? 0 : 1; k < world; ++k) NCCL_TRY(g_rccl.recv(g_comm.staging + (size_t)k * count, count, ncclUint8, k, g_comm.comm, st));
-        NCCL_TRY(g_rccl.group_end());
+        staging = sg.p;
+        // An error between ncclGroupStart and ncclGroupEnd must not leave the group open for every later call: the group is
+        // always closed, and the first error of the three stages is what the caller sees.
+        ncclResult_t first = g_rccl.group_start();
+        if (first != ncclSuccess) return api_fail(RT_ERR_DEVICE, std::string("ncclGroupStart: ") + g_rccl.error_string(first));
+        if (self) first = g_rccl.send(d_slices, count, ncclUint8, 0, g_comm.comm, st);
+        for (int k = self ? 0 : 1; k < world && first == ncclSuccess; ++k)
+            first = g_rccl.recv(staging + (size_t)k * count, count, ncclUint8, k, g_comm.comm, st);
+        const ncclResult_t closed = g_rccl.group_end();
+        if (first != ncclSuccess) return api_fail(RT_ERR_DEVICE, std::string("ncclSend / ncclRecv: ") + g_rccl.error_string(first));
+        if (closed != ncclSuccess) return api_fail(RT_ERR_DEVICE, std::string("ncclGroupEnd: ") + g_rccl.error_string(closed));
     }
-    return rt_deinterleave_device(self ? nullptr : d_slices, g_comm.staging, d_frames, frames, width, height, tile_rows, world, hip_stream);
+    if (ev) (void)hipEventRecord(ev->e[1], st);
+    const int rc = rt_deinterleave_device(self ? nullptr : d_slices, staging, d_frames, frames, width, height, tile_rows, world, hip_stream);
+    if (ev) (void)hipEventRecord(ev->e[2], st);
+    return rc;
+}
+
+int rt_gather_time(double* exchange_ms_out, double* deinterleave_ms_out, uint64_t* gathers_out) {
+    if (!exchange_ms_out || !deinterleave_ms_out || !gathers_out) return api_fail(RT_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    double ex = 0.0, de = 0.0;
+    uint64_t n = 0;
+    const size_t kept = g_comm.events_used < g_comm.events.size() ? g_comm.events_used : g_comm.events.size();
+    for (size_t i = 0; i < kept; ++i) {
+        float a = 0.f, b = 0.f;
+        hipError_t e = hipEventElapsedTime(&a, g_comm.events[i].e[0], g_comm.events[i].e[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&b, g_comm.events[i].e[1], g_comm.events[i].e[2]);
+        if (e != hipSuccess) return api_fail(RT_ERR_DEVICE, std::string("gather events (synchronise the gather streams first): ") + hipGetErrorString(e));
+        ex += a;
+        de += b;
+        ++n;
+    }
+    g_comm.events_used = 0;
+    *exchange_ms_out = ex;
+    *deinterleave_ms_out = de;
+    *gathers_out = n;
+    return RT_OK;
 }
 
 }  // extern "C"

@@ -757,8 +757,12 @@ __device__ __forceinline__ void node4_test(const NodeRegs& n, const RayF& f, flo
     }
 }
 
-// One traversal step at an interior node: returns the nearest child entered (or the next deferred one) and defers the
-// other entered children, farthest first, so that they are popped nearest first.
+// One traversal step at an interior node: returns the nearest child entered and defers the other entered children, farthest
+// first, so that they are popped nearest first.  When no child is entered: POP = true returns the next deferred entry
+// (closest_hit), POP = false returns kNoChild to callers that pop themselves (k_traverse: ONE pop loop per step, shared by the
+// lanes whose node had no child for them and the lanes that have just parked a leaf).
+constexpr int kNoChild = 0x7ffffffe;
+template <bool POP>
 __device__ __forceinline__ int node4_step(const NodeRegs& n, const RayF& f, float tmin, float tmax, TravStack& stack, int& sp) {
     float e[4];
     node4_test(n, f, tmin, tmax, e);
@@ -772,28 +776,7 @@ __device__ __forceinline__ int node4_step(const NodeRegs& n, const RayF& f, floa
     }
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-    if (e[0] == INFINITY) return stack.pop(sp, tmax);
-    const int deferred = (e[1] != INFINITY) + (e[2] != INFINITY) + (e[3] != INFINITY);
-    stack.push_sorted(sp, deferred, c[1], e[1], c[2], e[2], c[3], e[3]);
-    return c[0];
-}
-// node4_step for callers that pop themselves (k_traverse: ONE pop loop per step, shared by the lanes whose node had no child
-// for them and the lanes that have just parked a leaf): returns kNoChild instead of popping.
-constexpr int kNoChild = 0x7ffffffe;
-__device__ __forceinline__ int node4_step_nopop(const NodeRegs& n, const RayF& f, float tmin, float tmax, TravStack& stack, int& sp) {
-    float e[4];
-    node4_test(n, f, tmin, tmax, e);
-    int c[4] = {n.child[0], n.child[1], n.child[2], n.child[3]};
-#define RT_CSWAP(i, j)                                                      \
-    {                                                                       \
-        const bool sw = e[j] < e[i];                                        \
-        const float te = sw ? e[j] : e[i], tf_ = sw ? e[i] : e[j];          \
-        const int tc = sw ? c[j] : c[i], td = sw ? c[i] : c[j];             \
-        e[i] = te; e[j] = tf_; c[i] = tc; c[j] = td;                        \
-    }
-    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
-#undef RT_CSWAP
-    if (e[0] == INFINITY) return kNoChild;
+    if (e[0] == INFINITY) return POP ? stack.pop(sp, tmax) : kNoChild;
     const int deferred = (e[1] != INFINITY) + (e[2] != INFINITY) + (e[3] != INFINITY);
     stack.push_sorted(sp, deferred, c[1], e[1], c[2], e[2], c[3], e[3]);
     return c[0];
@@ -841,7 +824,7 @@ __device__ bool closest_hit(const DScene& S, const DParams& P, const Ray& r, dou
         while (static_cast<unsigned>(cur) < static_cast<unsigned>(kDone)) {  // 0 <= cur < kDone: interior node
             const NodeRegs n = load_node(&S.nodes[cur]);
             if (P.count_tests) { C.nodes += node4_children(n); C.visits++; }
-            cur = node4_step(n, rf, tmin32, tmax32, stack, sp);
+            cur = node4_step<true>(n, rf, tmin32, tmax32, stack, sp);
         }
         if (cur < 0) {  // leaf: one or two consecutive primitives
             int code = ~cur;

@@ -18,7 +18,6 @@ public:
     bool get_bool(const std::string& key, bool def) const;
 
 private:
-    void parse_line(std::string line, std::string& section);
     std::map<std::string, std::variant<int, double, bool>> data_;
 };
 

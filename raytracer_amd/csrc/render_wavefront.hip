@@ -581,7 +581,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 if (is_node) {
                     const NodeRegs nd = load_node(&S.nodes[cur]);
                     if (COUNT) { C.nodes += node4_children(nd); C.visits++; ray_visits++; }
-                    cur = node4_step_nopop(nd, rf, tmin32, tmax32, stack, sp);
+                    cur = node4_step<false>(nd, rf, tmin32, tmax32, stack, sp);
                     // one pop loop per step for both kinds of lanes that need their next deferred node: no child entered, or
                     // the nearest child is a leaf, which is parked
                     bool need = cur == kNoChild;
@@ -1173,11 +1173,12 @@ k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const Hi
 }
 
 // ------------------------------------------------------------------------------------------ k_resolve
-__global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ accum, uint8_t* __restrict__ out, const int npix,
+// (pixel counts reach 2^31 - 1 -- rt_render_frames_device: 4096 frames of a rank's share -- so every index is a size_t)
+__global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ accum, uint8_t* __restrict__ out, const size_t npix,
                                                     const int spp, const int mode) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= npix) return;
-    D3 c = mk(accum[i], accum[(size_t)npix + i], accum[2 * (size_t)npix + i]);
+    D3 c = mk(accum[i], accum[npix + i], accum[2 * npix + i]);
     D3 avg = tonemap(c * (1.0 / spp), mode);  // main.cpp:308-316
     out[i * 3 + 0] = quantise(avg.x);
     out[i * 3 + 1] = quantise(avg.y);
@@ -1216,11 +1217,11 @@ __global__ void __launch_bounds__(kBlock) k_make_xforms32(const DXform* __restri
 }
 
 // Linear radiance (the average before tone mapping) for float output and progressive accumulation.
-__global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const int n3,
+__global__ void __launch_bounds__(kBlock) k_resolve_linear(const double* __restrict__ accum, double* __restrict__ out, const size_t n3,
                                                            const int spp, const int add) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;   // interleaved RGB out, planes in
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;   // interleaved RGB out, planes in
     if (i >= n3) return;
-    const double v = accum[(size_t)(i % 3) * (size_t)(n3 / 3) + i / 3] * (1.0 / spp);
+    const double v = accum[(i % 3) * (n3 / 3) + i / 3] * (1.0 / spp);
     out[i] = add ? out[i] + v : v;   // add: a pass of a progressive render joins the running sum in HBM
 }
 
@@ -1273,7 +1274,9 @@ struct Driver {
     RayQ rays(int q, int level = 1) { return RayQ{static_cast<rt_q4*>(ws.queues[q]), (unsigned)ws.capacity, level == 0 ? 1u : 0u, chunk}; }
     HitQ hits(int q) { return HitQ{static_cast<rt_q4*>(ws.hit_buffers[q]), (unsigned)ws.capacity}; }
 
+    int fail_acquire_in = -1;   // tests (RT_TEST_PARTNER_FAIL=acquire): this many calls from now, acquire() reports the device full
     int acquire() {
+        if (fail_acquire_in >= 0 && fail_acquire_in-- == 0) { ok(hipErrorOutOfMemory); return -1; }
         for (size_t i = 0; i < ws.queues.size(); ++i)
             if (!ws.in_use[i]) { ws.in_use[i] = 1; return (int)i; }
         if (ws.fixed) { ok(hipErrorOutOfMemory); return -1; }   // the ray tree needs more queues than the caller's memory holds
@@ -1790,10 +1793,11 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     // so that one chunk's small launches and round trip hide behind the other's large launches (RT_ONE_CHUNK_AT_A_TIME: A/B).
     unsigned long long partner_rays = 0;
     bool partner_used = false;
+    bool partner_failed = false;   // the second set of queues could not be had (or ran out of memory mid-frame): this frame renders its chunks one by one
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool optimistic = attempt == 0 && may_emit && !ws.levels_overflowed && getenv("RT_SYNC_LEVELS") == nullptr;
         bool overflowed = false;
-        bool pairs = optimistic && chunks.size() >= 4 && !ws.fixed && !params.count_tests && getenv("RT_ONE_CHUNK_AT_A_TIME") == nullptr;
+        bool pairs = optimistic && !partner_failed && chunks.size() >= 4 && !ws.fixed && !params.count_tests && getenv("RT_ONE_CHUNK_AT_A_TIME") == nullptr;
         if (pairs && !ws.partner) {
             size_t free_bytes = 0, total_bytes = 0;
             const size_t workspace_bytes = ws.capacity * (4 * (sizeof(RayStore) + sizeof(HitRec)) + sizeof(Bundle));
@@ -1808,8 +1812,18 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             size_t mq2 = 0;
             w2.grow = ws.grow;
             w2.grown_capacity = ws.grown_capacity;
-            if ((e = prepare_workspace(scene, params, ws.partner_stream, w2, npix, may_emit, &mq2, false)) != hipSuccess) return e;
-            if (w2.capacity != ws.capacity) pairs = false;   // (cannot happen: same frame, same rules)
+            // The headroom was checked when the partner was created; frames, grown queues or the caller's own allocations may
+            // have used the device up since.  Without its partner a frame renders one chunk at a time: never an error.
+            const char* test_fail = getenv("RT_TEST_PARTNER_FAIL");   // tests: "prepare" = the partner cannot be had, "acquire" = it runs out mid-frame
+            if ((test_fail && strcmp(test_fail, "prepare") == 0) ||
+                prepare_workspace(scene, params, ws.partner_stream, w2, npix, may_emit, &mq2, false) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)drop_queues(w2, ws.partner_stream);
+                w2.capacity = 0;
+                pairs = false;
+            } else if (w2.capacity != ws.capacity) {
+                pairs = false;   // (cannot happen: same frame, same rules)
+            }
         }
         if (pairs) {
             WavefrontWorkspace& w2 = *ws.partner;
@@ -1818,6 +1832,7 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             D2.may_emit = D.may_emit; D2.max_capacity = D.max_capacity; D2.accum = ws.accum; D2.direct = D.direct;
             D2.variant = D.variant; D2.trav_variant = D.trav_variant; D2.shadow_variant = D.shadow_variant;
             D2.traverse_blocks = D.traverse_blocks; D2.K = D.K; D2.allow_grow = false;
+            if (const char* tf = getenv("RT_TEST_PARTNER_FAIL")) if (strcmp(tf, "acquire") == 0) D2.fail_acquire_in = 3;
             if (w2.events_used + 64 > kMaxTimedEvents) w2.events_used = 0;
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if ((e = hipEventCreateWithFlags(&ev0, hipEventDisableTiming)) != hipSuccess) return e;
@@ -1852,6 +1867,23 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
             (void)hipStreamWaitEvent(stream, ev1, 0);      // whatever follows on the caller's stream sees both halves
             (void)hipEventDestroy(ev0);
             (void)hipEventDestroy(ev1);
+            if (result2 < 0 && result1 >= 0 && D2.err == hipErrorOutOfMemory && !partner_failed) {
+                // The partner's lazily allocated queues did not fit the device any more.  Whatever both halves have added so far is
+                // dropped (as after a queue overflow) and the frame starts over on the caller's stream alone.
+                (void)hipGetLastError();
+                if ((e = hipStreamSynchronize(s2)) != hipSuccess || (e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+                (void)drop_queues(w2, s2);
+                w2.capacity = 0;
+                partner_failed = true;
+                for (char& u : ws.in_use) u = 0;
+                if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
+                if ((e = hipMemsetAsync(ws.stats + 3, 0, 5 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+                ws.events_used = first_event;
+                D.rays_traced = 0;
+                D.err = hipSuccess;
+                --attempt;
+                continue;
+            }
             if (result1 < 0 || result2 < 0) return D.err != hipSuccess ? D.err : (D2.err != hipSuccess ? D2.err : hipErrorUnknown);
             overflowed = result1 == 1 || result2 == 1;
             if (w2.levels_overflowed) { ws.levels_overflowed = true; ws.overflowed_scene = scene.serial; w2.levels_overflowed = false; }
@@ -1871,9 +1903,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (D.err != hipSuccess) return D.err;
     if (d_linear)
         hipLaunchKernelGGL(k_resolve_linear, dim3((unsigned)((npix * 3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_linear,
-                           (int)(npix * 3), params.spp, add_linear);
+                           npix * 3, params.spp, add_linear);
     else if (!D.direct)
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, (int)npix,
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ws.accum, d_rgb8, npix,
                            params.spp, params.tonemap);
     // Rays are counted on the host (every traversed queue entry is one closest-hit query).  With count_tests the call
     // also waits for the frame, reads the test counters and the traversal time of this frame's launches; without, it

@@ -65,6 +65,7 @@ class FrameGather:
         self.slices = torch.zeros((frames, self.max_rows, width, 3), dtype=torch.uint8, device=device)
         self.slice = self.slices[0]
         self.gathered, self.gather_buffer, self.frames, self.frame, self.index, self._parts = None, None, None, None, None, None
+        self.last_bytes_sent = 0
         # the library's exchange (RCCL + k_deinterleave) whenever its communicator spans this group
         self.native = self.world > 1 and self.slices.is_cuda and rt.comm_world() == self.world and rt.comm_rank() == self.rank
         if native is False:   # the caller found the library's communicator missing on some rank: torch.distributed's gather on all
@@ -87,27 +88,39 @@ class FrameGather:
                 flat = k[None, :] * (frames * self.max_rows) + b * self.max_rows + lr[None, :]   # [frames, H]
                 self.index = torch.from_numpy(np.ascontiguousarray(flat.reshape(-1))).to(device)
 
-    def run(self):
-        """Collective: call on every rank after its slices have been written.  Returns on rank 0 the frame (frames == 1)
-        or the batch of frames, else None."""
+    def run(self, nb=None):
+        """Collective: call on every rank after its slices have been written.  nb (default: the whole batch): only the
+        first nb frames of the set were rendered -- a partial last batch ships its own bytes, not the set's.  Returns on
+        rank 0 the frame (frames == 1) or the nb frames, else None."""
+        nb = self.batch if nb is None else int(nb)
+        if not 1 <= nb <= self.batch:
+            raise ValueError("FrameGather.run: nb must be 1 .. %d" % self.batch)
+        self.last_bytes_sent = nb * self.max_rows * self.width * 3 if self.world > 1 else 0   # this rank's message
         if self.world == 1:
-            return self.slice[: self.height] if self.batch == 1 else self.slices[:, : self.height]
+            return self.slice[: self.height] if self.batch == 1 else self.slices[:nb, : self.height]
         if self.native:
-            rt.gather_frames(self.slices.data_ptr(), self.batch, self.width, self.height, self.tile_rows,
+            rt.gather_frames(self.slices.data_ptr(), nb, self.width, self.height, self.tile_rows,
                              self.frames.data_ptr() if self.rank == 0 else None, stream=torch.cuda.current_stream().cuda_stream)
             if self.rank == 0:
-                return self.frame if self.batch == 1 else self.frames
+                return self.frame if self.batch == 1 else self.frames[:nb]
             return None
         if self.slices.is_cuda and dist.get_backend() == "gloo":
             # gloo gathers host tensors only (rehearsals of the multi-rank path on a box with fewer GPUs than ranks)
-            host = [torch.empty(self.slices.shape, dtype=torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(self.slices.cpu(), host, dst=0)
+            host = [torch.empty(self.slices[:nb].shape, dtype=torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(self.slices[:nb].cpu(), host, dst=0)
             if self.rank == 0:
                 for view, part in zip(self._parts, host):
-                    view.copy_(part)
-        else:
+                    view[:nb].copy_(part)
+        elif nb == self.batch:
             dist.gather(self.slices, self._parts, dst=0)
+        else:
+            parts = [torch.empty_like(self.slices[:nb]) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(self.slices[:nb].contiguous(), parts, dst=0)
+            if self.rank == 0:
+                for view, part in zip(self._parts, parts):
+                    view[:nb].copy_(part)
         if self.rank == 0:
-            torch.index_select(self.gather_buffer, 0, self.index, out=self.frames.view(self.batch * self.height, self.width, 3))
-            return self.frame if self.batch == 1 else self.frames
+            # the index is frame-major: its first nb * H entries rebuild the first nb frames
+            torch.index_select(self.gather_buffer, 0, self.index[: nb * self.height], out=self.frames[:nb].view(nb * self.height, self.width, 3))
+            return self.frame if self.batch == 1 else self.frames[:nb]
         return None

@@ -189,3 +189,28 @@ def test_pfm_endianness_and_scale():
     a = rt.read_pfm(os.path.join(helpers.GOLD, "Textures", "sky.pfm"))
     b = rt.read_pfm(os.path.join(helpers.GOLD, "Textures", "sky_be.pfm"))  # big-endian, scale 2 of half the values
     assert a.shape == (32, 64, 3) and np.allclose(a, b, rtol=1e-6)
+
+
+def test_config_reader_against_the_reference_class():
+    """tests/golden/config_cases.json: texts (the reference tree's own config files and the corner cases of its line grammar)
+    with the answers of the REFERENCE's Config class itself for every candidate key and all three getters, two defaults
+    each (oracle/gen_config_cases.py).  rt_config_* must give the same answers -- same keys stored, same types, same
+    prefix-parsed numbers, same defaults on a type mismatch."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_cases.json")) as f:
+        cases = json.load(f)
+    asked = held = 0
+    for case in cases:
+        cfg = rt.Config(text=case["text"])
+        for key, ans in case["answers"].items():
+            got_i = [cfg.get_int(key, -7), cfg.get_int(key, 13)]
+            got_d = [cfg.get_double(key, -7.5), cfg.get_double(key, 13.25)]
+            got_b = [int(cfg.get_bool(key, False)), int(cfg.get_bool(key, True))]
+            assert got_i == [int(v) for v in ans["i"]], (case["text"], key, got_i, ans["i"])
+            want_d = [float(v) for v in ans["d"]]
+            assert all((a == b) or (a != a and b != b) for a, b in zip(got_d, want_d)), (case["text"], key, got_d, ans["d"])
+            assert got_b == [int(v) for v in ans["b"]], (case["text"], key, got_b, ans["b"])
+            asked += 1
+            held += got_i[0] == got_i[1] or got_b[0] == got_b[1]
+    assert asked > 300 and held > 150

@@ -44,9 +44,26 @@ WORKER = textwrap.dedent("""
         for k in range(world):
             rt.part_scatter(fg.gathered[k].numpy()[: rt.part_rows(H, tile, k, world)], chk, tile, k, world)
         assert np.array_equal(chk, frame)
-        print("OK")
     else:
         assert out is None
+    if B > 1:
+        # a partial last batch: only the first nb frames of the set were rendered; they travel and are rebuilt alone, the
+        # message is nb (not B) frames' slices, and the rest of the frame buffers is left as it was
+        nb = B // 2
+        if rank == 0:
+            fg.frames[nb:] = 9
+        out = fg.run(nb)
+        assert fg.last_bytes_sent == nb * fg.max_rows * W * 3
+        if rank == 0:
+            assert tuple(out.shape) == (nb, H, W, 3) and np.array_equal(out.numpy(), frames[:nb]), "partial batch mismatch"
+            assert (fg.frames[nb:] == 9).all()
+        try:
+            fg.run(B + 1)
+            raise SystemExit("nb > batch accepted")
+        except ValueError:
+            pass
+    if rank == 0:
+        print("OK")
     dist.barrier()
     dist.destroy_process_group()
 """) % ROOT

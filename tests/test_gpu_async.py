@@ -223,6 +223,23 @@ def test_chunks_two_at_a_time_render_the_same_frame(gpu, name, monkeypatch):
         assert helpers.diff_stats(img, golden)[0] <= 1
 
 
+@pytest.mark.parametrize("how", ["prepare", "acquire"])
+def test_a_frame_that_loses_its_second_set_of_queues_still_renders(gpu, monkeypatch, how):
+    """The partner workspace of the chunk pairs is an optimisation, never a requirement: when it cannot be prepared (device
+    full) the frame renders its chunks one at a time; when one of its lazily allocated queues does not fit any more in the
+    middle of the frame, what both halves have added is dropped and the frame starts over alone -- same picture, same ray
+    count, no error (RT_TEST_PARTNER_FAIL simulates the two out-of-memory conditions)."""
+    scene_file, params, golden = helpers.load_case("c1_shadows_fresnel")
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    one, rays_one = _render_counted(scene_file, params, monkeypatch, True)
+    monkeypatch.setenv("RT_TEST_PARTNER_FAIL", how)
+    lost, rays_lost = _render_counted(scene_file, params, monkeypatch, False)
+    monkeypatch.delenv("RT_TEST_PARTNER_FAIL")
+    assert rays_lost == rays_one
+    mx, nd, _ = helpers.diff_stats(lost, one)
+    assert mx <= 1 and nd <= 0.001 * one.size and helpers.diff_stats(lost, golden)[0] <= 1
+
+
 def test_chunks_two_at_a_time_with_many_samples(gpu, monkeypatch):
     """16 spp through 4096-ray queues: chunks of one pixel row band split by sample batches add into the same pixels
     from both streams (FP64 atomics)."""

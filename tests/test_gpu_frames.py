@@ -129,3 +129,34 @@ def test_frames_cut_into_chunks(gpu, monkeypatch, name):
     for f in range(3):
         mx, nd, _ = helpers.diff_stats(got[f], one)
         assert mx <= 1 and nd <= 0.002 * one.size, (f, mx, nd)
+
+
+def test_more_than_a_third_of_2_31_pixels_per_call(gpu):
+    """346 frames of 1920x1080 are 717 M pixels: above 2^31 / 3, where a 32-bit `pixel * 3` byte offset in k_resolve wrapped
+    around (round 2) although the entry point admits up to 2^31 - 1 pixels per call.  Deterministic sampling: every frame of
+    the launch is the same picture, so the last slice must equal the first and the single frame (the frames go through the FP64
+    accumulators and k_resolve: the default scene reflects)."""
+    frames = 346
+    scene_file, params, golden = helpers.load_case("c1_1080p")
+    assert frames * 1080 * 1920 > (1 << 31) // 3
+    scene = rt.Scene(scene_file)
+    one = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=DEV)
+    out = torch.full((frames, 1080, 1920, 3), 7, dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize(DEV)
+    scene.render_device(params, one.data_ptr())
+    scene.render_frames_device(params, frames, out.data_ptr())
+    torch.cuda.synchronize(DEV)
+    scene.close()
+    rt.release_workspaces()
+    assert helpers.diff_stats(one.cpu().numpy(), golden)[0] <= 1
+    for f in (0, 1, frames // 2, frames - 2, frames - 1):
+        d = (out[f].to(torch.int16) - one.to(torch.int16)).abs()
+        assert int(d.max().item()) <= 1 and int((d > 0).sum().item()) <= 0.002 * one.numel(), f
+    buf = torch.zeros((2, 8, 1920, 3), dtype=torch.uint8, device=DEV)
+    with pytest.raises(rt.RtError) as e:   # 4096 frames x 1080 rows x 1920 pixels: beyond 2^31 pixels, refused
+        scene = rt.Scene(scene_file)
+        try:
+            scene.render_frames_device(params, 4096, buf.data_ptr())
+        finally:
+            scene.close()
+    assert e.value.code == rt.RT_ERR_LIMIT

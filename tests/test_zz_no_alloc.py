@@ -13,13 +13,21 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(scene, params, rows, width, stream):
+    """rt_render_device and rt_render_device_noalloc on the same input.  The headline property of the latter -- nothing is
+    allocated or freed on the device -- is checked with hipMemGetInfo around the call: the free bytes of the device do not
+    move (torch's caching allocator is not involved: the output buffers exist before the measurement)."""
     dev = torch.device("cuda", 0)
     a = torch.zeros((rows, width, 3), dtype=torch.uint8, device=dev)
     b = torch.full((rows, width, 3), 77, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
     scene.render_device(params, a.data_ptr(), stream=stream.cuda_stream)
-    scene.render_device_noalloc(params, b.data_ptr(), stream=stream.cuda_stream)
     torch.cuda.synchronize(dev)
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    scene.render_device_noalloc(params, b.data_ptr(), stream=stream.cuda_stream)
+    free_during = torch.cuda.mem_get_info(dev)[0]
+    torch.cuda.synchronize(dev)
+    free_after = torch.cuda.mem_get_info(dev)[0]
+    assert free_before == free_during == free_after, (free_before, free_during, free_after)
     return a.cpu().numpy(), b.cpu().numpy()
 
 
