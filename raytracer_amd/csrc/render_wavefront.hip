@@ -763,6 +763,85 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
     const double ad_weight = transparent ? 0.0 : (1.0 - M.reflectivity);
     const double refl_weight = transparent ? reflect_prob : M.reflectivity;
 
+    // ---- secondary rays.  They are queued BEFORE the local terms are computed: what the two parts share is the hit, the
+    // weight and a few scalars, and the vectors of the refraction / reflection geometry die here instead of staying in
+    // registers across the light loop below.  The random stream is the one of the old order: the light loop draws one
+    // number per light for its bundles, so the emission starts that many draws further on (splitmix64's state is a counter).
+    const int child_depth = q.depth - 1;
+    if (EMIT && child_depth > 0) {  // (children of depth 0 would return black without tracing, tracer.h:149)
+    Rng rng_e = rng;
+    if (P.shadows && S.n_lights > 0) rng_e.s += (unsigned long long)S.n_lights * 0x9E3779B97F4A7C15ull;
+    // reflection (tracer.h:176-219): samples below the surface are dropped (tracer.h:196-204), so the kept ones are found
+    // first with a copy of the random stream.  All children of the wave's hits then get their slots with one atomic,
+    // SAMPLE-major: the lanes that keep sample k take consecutive slots, so every store instruction of the wave writes
+    // consecutive 16-byte pieces (a lane's own rays side by side would put the lanes of an instruction 128 bytes and more
+    // apart, and the L2 passes such pieces on to memory one by one: measured, 6 x the bytes).
+    int samples = 0;
+    double rough = 0.0;
+    D3 perfect = mk(0, 0, 0), wr = mk(0, 0, 0), org = mk(0, 0, 0);
+    unsigned long long keep = 0ull;   // bit k < 62: reflection ray k of this hit; bit 62: TIR mirror ray; bit 63: refraction ray
+    if (has_refl) {
+        samples = P.glossy_samples;
+        if (q.depth < P.max_bounces) samples = 1;
+        rough = 1.0 / sqrt(M.shininess);
+        D3 Vn = normalize(r.d);
+        perfect = normalize(reflect(Vn, h.n));
+        wr = w * refl_weight;
+        if (M.is_metal) wr = cmul(wr, ld3(M.diffuse));
+        org = h.p + h.n * eps;
+        if (samples > 0) {
+            wr = wr * (1.0 / samples);
+            Rng dry = rng_e;
+            for (int k = 0; k < samples; ++k) {
+                D3 off = dry.in_unit_sphere() * rough;
+                D3 target = normalize(perfect + off);
+                if (dot(target, h.n) > 0) { keep |= 1ull << k; (void)dry.next(); }
+            }
+        } else {
+            keep = 1ull;
+        }
+    }
+    if (tir_mirror) keep |= 1ull << 62;
+    if (do_refract) keep |= 1ull << 63;
+    // how many rays the lanes of the wave that got here emit (ballots count only them), and one atomic for all
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int kmax = has_refl ? (samples > 0 ? samples : 1) : 0;   // reflection slots of this lane
+    unsigned total = (unsigned)__popcll(__ballot(tir_mirror)) + (unsigned)__popcll(__ballot(do_refract));
+    for (int k = 0; __ballot(k < kmax) != 0ull; ++k) total += (unsigned)__popcll(__ballot((keep >> k) & 1ull));
+    const int leader = __ffsll((long long)__ballot(1)) - 1;
+    unsigned slot0 = 0;
+    if (lane == leader && total != 0u) slot0 = atomicAdd(E.count, total);
+    slot0 = __shfl(slot0, leader);
+    for (int k = 0; __ballot(k < kmax) != 0ull; ++k) {
+        const unsigned long long mk_ = __ballot((keep >> k) & 1ull);
+        if (k < kmax) {
+            D3 target = perfect;
+            bool mine_k = true;
+            if (samples > 0) {
+                D3 off = rng_e.in_unit_sphere() * rough;
+                target = normalize(perfect + off);
+                mine_k = dot(target, h.n) > 0;
+            }
+            if (mine_k)
+                emit_ray_at(E.out, slot0 + (unsigned)__popcll(mk_ & below), E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng_e.next(), q.pixel,
+                            child_depth, kKindRadiance);
+        }
+        slot0 += (unsigned)__popcll(mk_);
+    }
+    {
+        const unsigned long long mt = __ballot(tir_mirror);
+        if (tir_mirror)  // tracer.h:258-264 (not tinted for metals)
+            emit_ray_at(E.out, slot0 + (unsigned)__popcll(mt & below), E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time,
+                        100000.0, rng_e.next(), q.pixel, child_depth, kKindRadiance);
+        slot0 += (unsigned)__popcll(mt);
+        const unsigned long long mr = __ballot(do_refract);
+        if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
+            emit_ray_at(E.out, slot0 + (unsigned)__popcll(mr & below), E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time,
+                        100000.0, rng_e.next(), q.pixel, child_depth, kKindRadiance);
+    }
+    }
+
     // ---- local shading: shading.h:104-217
     D3 base;
     if (Feat<F>::tex && M.texture >= 0) {
@@ -816,80 +895,6 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         }
     }
     contrib = cmul(w, ad * ad_weight + spec);
-
-    // ---- secondary rays
-    if (!EMIT) return true;
-    const int child_depth = q.depth - 1;
-    if (child_depth <= 0) return true;  // children would return black without tracing (tracer.h:149)
-    // reflection (tracer.h:176-219): samples below the surface are dropped (tracer.h:196-204), so the kept ones are found
-    // first with a copy of the random stream.  All children of the wave's hits then get their slots with one atomic,
-    // SAMPLE-major: the lanes that keep sample k take consecutive slots, so every store instruction of the wave writes
-    // consecutive 16-byte pieces (a lane's own rays side by side would put the lanes of an instruction 128 bytes and more
-    // apart, and the L2 passes such pieces on to memory one by one: measured, 6 x the bytes).
-    int samples = 0;
-    double rough = 0.0;
-    D3 perfect = mk(0, 0, 0), wr = mk(0, 0, 0), org = mk(0, 0, 0);
-    unsigned long long keep = 0ull;   // bit k < 62: reflection ray k of this hit; bit 62: TIR mirror ray; bit 63: refraction ray
-    if (has_refl) {
-        samples = P.glossy_samples;
-        if (q.depth < P.max_bounces) samples = 1;
-        rough = 1.0 / sqrt(M.shininess);
-        D3 Vn = normalize(r.d);
-        perfect = normalize(reflect(Vn, h.n));
-        wr = w * refl_weight;
-        if (M.is_metal) wr = cmul(wr, ld3(M.diffuse));
-        org = h.p + h.n * eps;
-        if (samples > 0) {
-            wr = wr * (1.0 / samples);
-            Rng dry = rng;
-            for (int k = 0; k < samples; ++k) {
-                D3 off = dry.in_unit_sphere() * rough;
-                D3 target = normalize(perfect + off);
-                if (dot(target, h.n) > 0) { keep |= 1ull << k; (void)dry.next(); }
-            }
-        } else {
-            keep = 1ull;
-        }
-    }
-    if (tir_mirror) keep |= 1ull << 62;
-    if (do_refract) keep |= 1ull << 63;
-    // how many rays the lanes of the wave that got here emit (ballots count only them), and one atomic for all
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int kmax = has_refl ? (samples > 0 ? samples : 1) : 0;   // reflection slots of this lane
-    unsigned total = (unsigned)__popcll(__ballot(tir_mirror)) + (unsigned)__popcll(__ballot(do_refract));
-    for (int k = 0; __ballot(k < kmax) != 0ull; ++k) total += (unsigned)__popcll(__ballot((keep >> k) & 1ull));
-    const int leader = __ffsll((long long)__ballot(1)) - 1;
-    unsigned slot0 = 0;
-    if (lane == leader && total != 0u) slot0 = atomicAdd(E.count, total);
-    slot0 = __shfl(slot0, leader);
-    for (int k = 0; __ballot(k < kmax) != 0ull; ++k) {
-        const unsigned long long mk_ = __ballot((keep >> k) & 1ull);
-        if (k < kmax) {
-            D3 target = perfect;
-            bool mine_k = true;
-            if (samples > 0) {
-                D3 off = rng.in_unit_sphere() * rough;
-                target = normalize(perfect + off);
-                mine_k = dot(target, h.n) > 0;
-            }
-            if (mine_k)
-                emit_ray_at(E.out, slot0 + (unsigned)__popcll(mk_ & below), E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng.next(), q.pixel,
-                            child_depth, kKindRadiance);
-        }
-        slot0 += (unsigned)__popcll(mk_);
-    }
-    {
-        const unsigned long long mt = __ballot(tir_mirror);
-        if (tir_mirror)  // tracer.h:258-264 (not tinted for metals)
-            emit_ray_at(E.out, slot0 + (unsigned)__popcll(mt & below), E.cap, E.overflow, h.p + Nh * eps, normalize(reflect(Vin, Nh)), w * reflect_prob, q.time,
-                        100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
-        slot0 += (unsigned)__popcll(mt);
-        const unsigned long long mr = __ballot(do_refract);
-        if (do_refract)  // tracer.h:239-245: starts at the hit point, tinted by diffuse
-            emit_ray_at(E.out, slot0 + (unsigned)__popcll(mr & below), E.cap, E.overflow, h.p, normalize(refr_dir), cmul(w * transmit_prob, ld3(M.diffuse)), q.time,
-                        100000.0, rng.next(), q.pixel, child_depth, kKindRadiance);
-    }
     return true;
 }
 
@@ -898,8 +903,11 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 // other with the same pixel -- the samples of one pixel and their children stay neighbours in the queues -- are summed
 // inside the wave first and only the first lane of each run issues the three atomics.
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 1          // waves per SIMD asked of the register allocator for the shading kernel
-#endif
+#define RT_SHADE_WAVES 3          // waves per SIMD asked of the register allocator for the shading kernel that queues rays, analytic
+#endif                            // shapes: 200 registers without a bound (two waves); held to 168 it spills a little and C3 / C1 gain 1-2 %
+#ifndef RT_SHADE_TEX_WAVES
+#define RT_SHADE_TEX_WAVES 2      // ... of its variants with textures, the ray marcher or the environment: 256 / 272 registers without
+#endif                            // a bound -- the full variant then runs ONE wave per SIMD (C4 3.53 ms; held to 256: 3.21 ms); 3 spills badly (C5 + 8 %)
 #ifndef RT_SHADE_LEAN_WAVES
 #define RT_SHADE_LEAN_WAVES 4     // ... for the variant that cannot queue a ray (no emission code: 136 registers without a bound)
 #endif
@@ -907,7 +915,7 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 // level less -- was built and measured: the kernel grows from 223 to 255 registers and C3 at 16 spp takes 47.6 instead of
 // 40.3 ms, C1 0.67 instead of 0.66 ms: the traversal loop runs better at its own 4 waves per SIMD than inside this kernel's 2.)
 template <int F, bool EMIT, bool SMALL>
-__global__ void __launch_bounds__(kBlock, EMIT ? RT_SHADE_WAVES : ((F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_WAVES : RT_SHADE_LEAN_WAVES)) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
+__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_TEX_WAVES : EMIT ? RT_SHADE_WAVES : RT_SHADE_LEAN_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
                                                   const HitQ hits_all, const QIn in, const EmitCtx E, double* __restrict__ accum) {
     __shared__ SceneStage<SMALL> staged;
     const BlockSpan span = block_span(in);
@@ -1240,7 +1248,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve_sum(const double* __restrict
 constexpr int kSpheres = RT_FEAT_SPHERE;
 constexpr int kAnalytic = RT_FEAT_SPHERE | RT_FEAT_QUAD | RT_FEAT_CUBE;
 constexpr int kFull = kAnalytic | RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV;
-constexpr int kTextured = kAnalytic | RT_FEAT_TEXTURE;   // k_shadow only: analytic shapes whose transmitting occluders may carry bump maps
+constexpr int kTextured = kAnalytic | RT_FEAT_TEXTURE;   // analytic shapes with textures / bump maps (k_shade; k_shadow where transmitting occluders may carry bump maps)
 
 constexpr size_t kMaxTimedEvents = 8192;   // start/stop events kept per workspace until they are collected
 constexpr size_t kMinQueueRays = size_t(1) << 16;
@@ -1368,7 +1376,7 @@ struct Driver {
     bool small_scene() const { return S.n_prims <= kSmallScenePrims && small_env_ok; }
     // (A/B runs) workgroups per CU of the grids of the shading kernel that queues rays -- 2 are resident at its 220 registers: 1-2 %
     // faster than 8 on every config -- and of k_shadow (default: what is resident, see launch_shadow)
-    const int shade_grid_per_cu = getenv("RT_SHADE_GRID_PER_CU") ? atoi(getenv("RT_SHADE_GRID_PER_CU")) : 2;
+    const int shade_grid_per_cu = getenv("RT_SHADE_GRID_PER_CU") ? atoi(getenv("RT_SHADE_GRID_PER_CU")) : 0;   // 0: what is resident
     const int shadow_grid_per_cu = getenv("RT_SHADOW_GRID_PER_CU") ? atoi(getenv("RT_SHADOW_GRID_PER_CU")) : 0;
     // children of a launch go to queue qo (the queue of level `out_level`), its bundles to the bundle buffer
     EmitCtx emit_ctx(int qo, int out_level) {
@@ -1400,7 +1408,8 @@ struct Driver {
     template <int F> void launch_shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
         const int level = out_level - 1;
         const EmitCtx E = emit_ctx(qo, out_level);
-        const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi), may_emit ? shade_grid_per_cu : 0));
+        constexpr int kResident = (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_TEX_WAVES : RT_SHADE_WAVES;
+        const dim3 grid(grid_for(in, in.counts ? bound : in.hi - std::min(in.lo, in.hi), may_emit ? (shade_grid_per_cu > 0 ? shade_grid_per_cu : kResident) : 0));
         const QIn& v = in;
         if (may_emit && small_scene())
             hipLaunchKernelGGL((k_shade<F, true, true>), grid, dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), v, E, accum);
@@ -1420,6 +1429,7 @@ struct Driver {
     void shade(int q, const QIn& in, unsigned bound, int qo, int out_level) {
         if (variant == 0) launch_shade<kSpheres>(q, in, bound, qo, out_level);
         else if (variant == 1) launch_shade<kAnalytic>(q, in, bound, qo, out_level);
+        else if (variant == 3) launch_shade<kTextured>(q, in, bound, qo, out_level);
         else launch_shade<kFull>(q, in, bound, qo, out_level);
     }
     // entries in all shards of the queue of `level` -> the word next to the overflow flag (read back together)
@@ -1737,7 +1747,9 @@ hipError_t launch_render_wavefront(const DScene& scene, const DParams& params, u
     if (!D.may_emit && params.spp == 1 && !d_linear) D.direct = d_rgb8;
     else if ((e = hipMemsetAsync(ws.accum, 0, npix * 3 * sizeof(double), stream)) != hipSuccess) return e;
     const int f = scene.features;
-    D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : 2;
+    // shading: spheres only / analytic shapes / analytic shapes with textures or bump maps (no ray marcher, no environment: the floor
+    // texture of config 5 must not cost it the 278 registers -- one wave per SIMD -- of the full variant) / everything
+    D.variant = ((f & ~kSpheres) == 0) ? 0 : ((f & ~kAnalytic) == 0) ? 1 : ((f & ~kTextured) == 0) ? 3 : 2;
     D.trav_variant = (f & RT_FEAT_COMPLEX) ? 2 : (f & (RT_FEAT_QUAD | RT_FEAT_CUBE)) ? 1 : 0;
     D.shadow_variant = (f & RT_FEAT_COMPLEX) ? 2 : ((f & RT_FEAT_TEXTURE) && scene.transparent_materials != 0) ? 3 : D.trav_variant;
     if (getenv("RT_NO_GEOMETRY_VARIANTS")) D.trav_variant = D.shadow_variant = D.variant;   // (A/B runs)
