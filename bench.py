@@ -462,7 +462,7 @@ def main():
         dist.barrier()
 
     # one frame at a time (latency setting) and the boundary's own contract -- rt_render into a HOST buffer (main.cpp:242,320)
-    solo_ms, host_ms, traverse_ms_one_frame, normals_ms, fp32_variant = None, None, None, None, None
+    solo_ms, host_ms, traverse_ms_one_frame, normals_ms, fp32_variant, host_frames_ms = None, None, None, None, None, {}
     if world == 1:
         torch.cuda.synchronize(dev)
         n_solo = max(5, min(args.steps, 20))
@@ -478,11 +478,25 @@ def main():
         traverse_ms_one_frame = ms / max(1, n1)
         p_host = params.copy()
         p_host.part_count, p_host.part_index = 1, 0
-        scene.render(p_host)
+        host_buf = np.zeros((H, W, 3), dtype=np.uint8)   # one buffer, reused, as a render loop would
+        for _ in range(2):
+            scene.render(p_host, out=host_buf)
         t1 = time.perf_counter()
         for _ in range(n_solo):
-            scene.render(p_host)
+            scene.render(p_host, out=host_buf)
         host_ms = (time.perf_counter() - t1) * 1e3 / n_solo
+        # ... and rt_render_frames: F frames per call into host memory, batches that share their launches, the copy of one batch
+        # (pinned staging + the host's memcpy into the caller's buffer) behind the render of the next
+        host_frames_ms = {}
+        for F in (4, 16, 64):
+            host_many = np.zeros((F, H, W, 3), dtype=np.uint8)
+            scene.render_frames(p_host, F, out=host_many)
+            reps = max(2, 32 // F)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                scene.render_frames(p_host, F, out=host_many)
+            host_frames_ms[F] = (time.perf_counter() - t1) * 1e3 / (reps * F)
+            del host_many
         # the same frames with --normals (the other flag set of config 2), B per launch like the headline
         p_n = params.copy()
         p_n.normals = 1
@@ -589,6 +603,7 @@ def main():
             "ms_per_frame_solo": round(solo_ms, 4) if solo_ms else None,
             "Mrays_per_s_solo": round(rays_frame / solo_ms / 1e3, 1) if solo_ms else None,
             "ms_per_frame_host_buffer": round(host_ms, 4) if host_ms else None,
+            "ms_per_frame_host_buffer_frames_per_call": {str(k): round(v, 4) for k, v in host_frames_ms.items()} or None,
             "ms_per_frame_normals_flag": round(normals_ms, 4) if normals_ms else None,
             "Mrays_per_s_normals_flag": round(rays_frame / normals_ms / 1e3, 1) if normals_ms else None,
             "fp32_variant": fp32_variant,

@@ -289,6 +289,18 @@ int rt_bvh_order_device(const RtSceneDesc* desc, int32_t* order_out, double* dev
  * owned by part_index are written; the rest of the buffer is left untouched.  stats may be NULL. */
 int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats);
 
+/* `frames` whole frames of the same scene into host memory, frame f with seed params->seed + f: rgb8_out receives
+ * frames x H x W x 3 bytes, frame after frame, each as rt_render writes it.  What the reference does with `--time N`
+ * (main.cpp:486-507: render_scene_func N times) when the frames are wanted, and the throughput form of the drop-in: the frames
+ * are rendered in batches that share one set of launches (rt_render_frames_device) and the device -> host copy of a batch
+ * overlaps the render of the next.  Wavefront schedule, whole frames (part_count <= 1).  stats (may be NULL): rays and device
+ * time of all frames together.
+ * Both rt_render and rt_render_frames register the caller's buffer with the driver the second time they see it (hipHostRegister;
+ * a render loop passes the same buffer again and again; at most 8 ranges are kept, least recently used first out, all
+ * released by rt_shutdown) so that the copy is one DMA instead of the runtime's staged pageable copy.  Environment
+ * RT_HOST_REGISTER=always registers at first sight, =never not at all. */
+int rt_render_frames(rt_scene_t scene, const RtRenderParams* params, int frames, uint8_t* rgb8_out, RtStats* stats);
+
 /* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t with HIP's own meaning: NULL is
  * the null stream, which is also PyTorch's default stream, so whatever the caller enqueues there afterwards is ordered
  * behind the render): d_rgb8 receives this part's rows compacted in tile order (rt_part_rows() rows of W*3 bytes) — the slice

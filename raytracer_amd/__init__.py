@@ -121,7 +121,7 @@ ABI_SYMBOLS = [
     "rt_set_bvh_builder", "rt_scene_bvh_nodes", "rt_bvh_order_device", "rt_render_device_noalloc", "rt_render_frames_device", "rt_reserve",
     "rt_release_workspaces", "rt_comm_unique_id", "rt_comm_init", "rt_comm_rank", "rt_comm_world", "rt_comm_destroy",
     "rt_gather_frames", "rt_deinterleave_device", "rt_render_gathered", "rt_accumulate_device", "rt_resolve_sum_device",
-    "rt_gather_time",
+    "rt_gather_time", "rt_render_frames",
 ]
 
 
@@ -169,6 +169,7 @@ def _load():
         "rt_bvh_order_device": (i32, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
         "rt_render": (i32, [vp, C.POINTER(RtRenderParams), vp, C.POINTER(RtStats)]),
         "rt_render_device": (i32, [vp, C.POINTER(RtRenderParams), vp, vp, i32, vp]),
+        "rt_render_frames": (i32, [vp, C.POINTER(RtRenderParams), i32, vp, C.POINTER(RtStats)]),
         "rt_render_device_noalloc": (i32, [vp, C.POINTER(RtRenderParams), vp, vp]),
         "rt_render_frames_device": (i32, [vp, C.POINTER(RtRenderParams), i32, i32, vp, vp, vp]),
         "rt_reserve": (i32, [vp, C.c_uint64, i32]), "rt_release_workspaces": (i32, []),
@@ -521,12 +522,23 @@ class Scene:
         return {"nodes": nodes[: info.n_nodes], "info": info, "root_ref": b.root_ref, "pad": b.pad, "builder": names[b.builder],
                 "device_build_ms": b.device_build_ms, "order_on_device": bool(b.order_on_device), "device_order_ms": b.device_order_ms}
 
-    def render(self, params, stats=False):
-        """One frame -> uint8 [H, W, 3] (the bytes Image::write would store).  stats=True also returns RtStats."""
-        img = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+    def render(self, params, stats=False, out=None):
+        """One frame -> uint8 [H, W, 3] (the bytes Image::write would store).  stats=True also returns RtStats.  `out`: a
+        buffer to reuse, as a render loop would (the library keeps it registered with the driver between calls)."""
+        img = np.zeros((self.height, self.width, 3), dtype=np.uint8) if out is None else out
         st = RtStats()
         _check(lib.rt_render(self._h, C.byref(params), img.ctypes.data, C.byref(st) if stats else None))
         return (img, st) if stats else img
+
+    def render_frames(self, params, frames, out=None, stats=False):
+        """`frames` whole frames (seeds params.seed + f) -> uint8 [frames, H, W, 3] in host memory (rt_render_frames); `out`: a
+        buffer to reuse (the library keeps it registered with the driver between calls)."""
+        if out is None:
+            out = np.zeros((frames, self.height, self.width, 3), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.shape == (frames, self.height, self.width, 3)
+        st = RtStats()
+        _check(lib.rt_render_frames(self._h, C.byref(params), int(frames), out.ctypes.data, C.byref(st) if stats else None))
+        return (out, st) if stats else out
 
     def render_gathered(self, params, stats=False):
         """Collective over the library's communicator: every rank renders its tiles, rank 0 returns the whole frame (the

@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -47,10 +48,134 @@ struct DeviceState {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // rt_render_frames: device -> host copies of one batch while the next one renders
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t rendered[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};   // rt_render_frames: per slice set
     uint64_t* d_counters = nullptr;  // RT_N_COUNTERS x u64
+    // Pinned host staging of rt_render_frames (hipHostMalloc): a device -> host copy into it is one DMA at the link's rate and
+    // truly asynchronous, which a copy into the caller's pageable buffer is not (the runtime stages it and the call blocks);
+    // the host thread moves a batch on into the caller's buffer while the GPU renders the next one.
+    uint8_t* staging[2] = {nullptr, nullptr};
+    size_t staging_bytes = 0;
 };
 DeviceState g_dev;
+
+// The caller's frame buffer is ordinary (pageable) host memory: `Image::m_pixel_data` is a std::vector (Image.h:46-47).  A
+// device -> host copy into pageable memory goes through the runtime's own staging buffers at a fraction of the link's rate
+// (6.2 MB of a 1080p frame: ~0.5 ms); into memory that is registered with the driver it is one DMA (~0.15 ms).  So the
+// buffers rt_render / rt_render_frames are handed are registered on first use and stay registered -- a render loop passes
+// the same buffer again and again -- up to kMaxPins of them (the least recently used one is unregistered), until
+// rt_shutdown.  Registration is by address range: a buffer that was freed and whose range is handed out again is simply
+// registered memory still (the driver follows the range, not the allocation); should a copy into a cached range ever fail,
+// the range is dropped and the copy repeated the pageable way.  RT_NO_HOST_REGISTER=1 turns the cache off.
+struct HostPin {
+    uintptr_t base = 0;
+    size_t bytes = 0;
+    unsigned long long used = 0;
+    bool ours = true;   // false: the caller had registered it itself (left alone)
+};
+constexpr size_t kMaxPins = 8, kMinPinBytes = size_t(256) << 10;
+std::vector<HostPin> g_pins;
+std::vector<HostPin> g_seen;   // ranges seen once (nothing is registered for these yet)
+std::mutex g_pin_mutex;
+unsigned long long g_pin_clock = 0;
+
+void unpin_all() {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (const HostPin& p : g_pins)
+        if (p.ours) (void)hipHostUnregister(reinterpret_cast<void*>(p.base));
+    g_pins.clear();
+    g_seen.clear();
+}
+void unpin(void* host) {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(host);
+    for (size_t i = 0; i < g_pins.size(); ++i)
+        if (a >= g_pins[i].base && a < g_pins[i].base + g_pins[i].bytes) {
+            if (g_pins[i].ours) (void)hipHostUnregister(reinterpret_cast<void*>(g_pins[i].base));
+            g_pins.erase(g_pins.begin() + static_cast<long>(i));
+            return;
+        }
+}
+// true: [host, host + bytes) is registered with the driver now.  A buffer is registered the SECOND time it is seen (a render
+// loop's buffer; registering costs about as much as one pageable copy, so a buffer that is used once is better off without);
+// RT_HOST_REGISTER=always registers at first sight, =never (or RT_NO_HOST_REGISTER=1) not at all.
+bool pin_host(void* host, size_t bytes) {
+    static const int mode = [] {
+        const char* e = std::getenv("RT_HOST_REGISTER");
+        if (std::getenv("RT_NO_HOST_REGISTER") || (e && std::string(e) == "never")) return 0;
+        return (e && std::string(e) == "always") ? 2 : 1;
+    }();
+    if (mode == 0 || !host || bytes < kMinPinBytes) return false;
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(host);
+    for (HostPin& p : g_pins)
+        if (a >= p.base && a + bytes <= p.base + p.bytes) { p.used = ++g_pin_clock; return true; }
+    if (mode == 1) {
+        bool seen = false;
+        for (size_t i = 0; i < g_seen.size(); ++i)
+            if (g_seen[i].base == a && g_seen[i].bytes == bytes) { seen = true; g_seen.erase(g_seen.begin() + static_cast<long>(i)); break; }
+        if (!seen) {
+            if (g_seen.size() >= kMaxPins) g_seen.erase(g_seen.begin());
+            g_seen.push_back(HostPin{a, bytes, 0, false});
+            return false;
+        }
+    }
+    // a range that overlaps a cached one without lying inside it (the caller's buffer grew or moved a little): drop the old one
+    for (size_t i = 0; i < g_pins.size();) {
+        if (a < g_pins[i].base + g_pins[i].bytes && g_pins[i].base < a + bytes) {
+            if (g_pins[i].ours) (void)hipHostUnregister(reinterpret_cast<void*>(g_pins[i].base));
+            g_pins.erase(g_pins.begin() + static_cast<long>(i));
+        } else {
+            ++i;
+        }
+    }
+    if (g_pins.size() >= kMaxPins) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_pins.size(); ++i) if (g_pins[i].used < g_pins[lru].used) lru = i;
+        if (g_pins[lru].ours) (void)hipHostUnregister(reinterpret_cast<void*>(g_pins[lru].base));
+        g_pins.erase(g_pins.begin() + static_cast<long>(lru));
+    }
+    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess || e == hipErrorHostMemoryAlreadyRegistered) {
+        if (e != hipSuccess) (void)hipGetLastError();
+        g_pins.push_back(HostPin{a, bytes, ++g_pin_clock, e == hipSuccess});
+        return true;
+    }
+    (void)hipGetLastError();   // cannot be registered (e.g. a read-only mapping): the pageable copy still works
+    return false;
+}
+// memcpy of a batch of frames from the pinned staging buffer into the caller's buffer: one thread moves ~10 GB/s, which would bound
+// rt_render_frames at ~0.6 ms per 1080p frame; pieces of 16 MB and more go to up to four threads.
+void host_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+    const size_t threads = std::min<size_t>(4, bytes / (size_t(16) << 20));
+    if (threads < 2) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> pool;
+    const size_t piece = (bytes / threads + 4095) & ~size_t(4095);
+    try {
+        for (size_t t = 1; t < threads; ++t) {
+            const size_t b = t * piece, e = std::min(bytes, b + piece);
+            if (b < e) pool.emplace_back([=] { std::memcpy(dst + b, src + b, e - b); });
+        }
+    } catch (...) {   // no thread to be had: this one copies the rest
+        size_t done = (pool.size() + 1) * piece;
+        if (done < bytes) std::memcpy(dst + done, src + done, bytes - done);
+    }
+    std::memcpy(dst, src, std::min(bytes, piece));
+    for (std::thread& th : pool) th.join();
+}
+
+// Device -> host copy of a frame (or several) into the caller's buffer on `st`, through the registration cache.
+hipError_t copy_out(void* host, const void* dev, size_t bytes, hipStream_t st) {
+    const bool pinned = pin_host(host, bytes);
+    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess && pinned) {   // a stale range: forget it and copy the ordinary way
+        (void)hipGetLastError();
+        unpin(host);
+        e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+    }
+    return e;
+}
 
 // Workspaces of the wavefront schedule (ray queues, accumulators, counters): one per HIP stream, process-wide, so that
 // they outlive the scenes rendered through them -- a service that opens and closes scenes keeps its queues, and the
@@ -104,6 +229,8 @@ struct rt_scene_s {
     std::vector<void*> allocations;   // everything to hipFree
     uint8_t* d_frame = nullptr;       // scratch framebuffer for rt_render
     size_t d_frame_bytes = 0;
+    uint8_t* d_batch[2] = {nullptr, nullptr};   // rt_render_frames: two sets of frame slices that alternate
+    size_t d_batch_bytes = 0;
     bool on_device = false;
 };
 struct rt_config_s {
@@ -319,8 +446,13 @@ int rt_init(int device_id) {
     if (g_dev.ready) rt_shutdown();
     g_dev.device = dev;
     HIP_TRY(hipStreamCreateWithFlags(&g_dev.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g_dev.copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g_dev.ev0));
     HIP_TRY(hipEventCreate(&g_dev.ev1));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&g_dev.rendered[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_dev.copied[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_dev.d_counters), RT_N_COUNTERS * sizeof(uint64_t)));
     HIP_TRY(wavefront_static_setup(dev));   // device address of the static scratch array of rt_render_device_noalloc
     g_dev.ready = true;
@@ -351,9 +483,16 @@ int rt_reserve(void* hip_stream, uint64_t rays_per_queue, int n_queues) {
 void rt_shutdown(void) {
     if (!g_dev.ready) return;
     (void)rt_release_workspaces();
+    unpin_all();
     if (g_dev.stream) (void)hipStreamDestroy(g_dev.stream);
+    if (g_dev.copy_stream) (void)hipStreamDestroy(g_dev.copy_stream);
     if (g_dev.ev0) (void)hipEventDestroy(g_dev.ev0);
     if (g_dev.ev1) (void)hipEventDestroy(g_dev.ev1);
+    for (int i = 0; i < 2; ++i) {
+        if (g_dev.rendered[i]) (void)hipEventDestroy(g_dev.rendered[i]);
+        if (g_dev.copied[i]) (void)hipEventDestroy(g_dev.copied[i]);
+        if (g_dev.staging[i]) (void)hipHostFree(g_dev.staging[i]);
+    }
     if (g_dev.d_counters) (void)hipFree(g_dev.d_counters);
     g_dev = DeviceState();
 }
@@ -578,6 +717,7 @@ void rt_scene_destroy(rt_scene_t scene) {
         (void)hipSetDevice(g_dev.device);
         for (void* p : scene->allocations) (void)hipFree(p);
         if (scene->d_frame) (void)hipFree(scene->d_frame);
+        for (uint8_t* p : scene->d_batch) if (p) (void)hipFree(p);
     }
     delete scene;
 }
@@ -924,9 +1064,11 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
     std::vector<uint8_t> slice;
     uint8_t* dst = rgb8_out;
     if (parts > 1) { slice.resize(bytes); dst = slice.data(); }
-    if (bytes) HIP_TRY(hipMemcpyAsync(dst, scene->d_frame, bytes, hipMemcpyDeviceToHost, g_dev.stream));
+    // (Through the pinned staging buffer of rt_render_frames and one memcpy instead: measured the same, 1.50 against 1.52 ms for the
+    // C2 frame -- the runtime's own staged copy into pageable memory already overlaps its DMA with its memcpy.)
+    if (bytes) HIP_TRY(copy_out(dst, scene->d_frame, bytes, g_dev.stream));
     uint64_t counters[RT_N_COUNTERS] = {};
-    HIP_TRY(hipMemcpyAsync(counters, g_dev.d_counters, sizeof(counters), hipMemcpyDeviceToHost, g_dev.stream));
+    if (stats) HIP_TRY(hipMemcpyAsync(counters, g_dev.d_counters, sizeof(counters), hipMemcpyDeviceToHost, g_dev.stream));
     HIP_TRY(hipStreamSynchronize(g_dev.stream));
     if (parts > 1 && bytes) {
         rc = rt_part_scatter(slice.data(), rgb8_out, scene->width, scene->height, tile, params->part_index, parts);
@@ -942,6 +1084,93 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
         stats->rays_coincident = counters[7];
         stats->kernel_ms = ms;
         stats->traverse_ms = static_cast<double>(counters[3]) * 1e-6;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+// `frames` frames of one scene into host memory: the frames are rendered in batches (rt_render_frames_device: the rays of a
+// batch share one set of launches and one tail of the traversal kernel) into two sets of slices that alternate, and the
+// device -> host copy of a batch runs on a stream of its own while the next batch renders.
+int rt_render_frames(rt_scene_t scene, const RtRenderParams* params, int frames, uint8_t* rgb8_out, RtStats* stats) {
+    if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    if (!scene || !params || !rgb8_out) return fail(RT_ERR_INVALID, "NULL argument");
+    if (frames < 1) return fail(RT_ERR_INVALID, "frames must be >= 1");
+    if (params->part_count > 1) return fail(RT_ERR_INVALID, "rt_render_frames renders whole frames (use rt_render_frames_device for parts)");
+    if (params->schedule == RT_SCHEDULE_MEGAKERNEL) return fail(RT_ERR_INVALID, "rt_render_frames renders with the wavefront schedule");
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(g_dev.device));
+    const size_t frame_bytes = static_cast<size_t>(scene->height) * scene->width * 3;
+    // batches of at most 16 frames (what one launch gains from more is small: DESIGN section 5), and at least two batches when
+    // there are frames enough, so that a copy has a render to hide behind
+    int batch = std::min(frames, 16);
+    if (frames >= 4 && frames <= 16) batch = (frames + 1) / 2;
+    const size_t need = frame_bytes * static_cast<size_t>(batch);
+    if (scene->d_batch_bytes < need) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (uint8_t*& p : scene->d_batch) { if (p) (void)hipFree(p); p = nullptr; }
+        scene->d_batch_bytes = 0;
+        for (uint8_t*& p : scene->d_batch) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), need));
+        scene->d_batch_bytes = need;
+    }
+    // Where the copies go: straight into the caller's buffer when it is (or can be) registered with the driver, else through
+    // the pinned staging pair (this pool's driver refuses hipHostRegister: "invalid argument").
+    const bool direct = pin_host(rgb8_out, frame_bytes * static_cast<size_t>(frames));
+    if (!direct && g_dev.staging_bytes < need) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (uint8_t*& p : g_dev.staging) { if (p) (void)hipHostFree(p); p = nullptr; }
+        g_dev.staging_bytes = 0;
+        for (uint8_t*& p : g_dev.staging) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p), need, hipHostMallocDefault));
+        g_dev.staging_bytes = need;
+    }
+    HIP_TRY(hipMemsetAsync(g_dev.d_counters, 0, RT_N_COUNTERS * sizeof(uint64_t), g_dev.stream));
+    HIP_TRY(hipEventRecord(g_dev.ev0, g_dev.stream));
+    RtRenderParams q = *params;
+    q.part_index = 0; q.part_count = 1;
+    // what lies in staging set s and where it belongs: moved on by the host once the set's copy has arrived
+    struct Pending { uint8_t* dst = nullptr; size_t bytes = 0; } pending[2];
+    auto drain = [&](int set) -> hipError_t {
+        if (!pending[set].dst) return hipSuccess;
+        const hipError_t e = hipEventSynchronize(g_dev.copied[set]);
+        if (e != hipSuccess) return e;
+        host_copy(pending[set].dst, g_dev.staging[set], pending[set].bytes);
+        pending[set].dst = nullptr;
+        return hipSuccess;
+    };
+    int k = 0;
+    for (int f = 0; f < frames; f += batch, ++k) {
+        const int nb = std::min(batch, frames - f), set = k & 1;
+        if (!direct) HIP_TRY(drain(set));                                            // staging set free again (batch k - 2)
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(g_dev.stream, g_dev.copied[set], 0));   // the set's previous frames have left the device
+        q.seed = params->seed + static_cast<uint64_t>(f);
+        int rc = rt_render_frames_device(scene, &q, nb, 0, scene->d_batch[set], g_dev.d_counters, g_dev.stream);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipEventRecord(g_dev.rendered[set], g_dev.stream));
+        HIP_TRY(hipStreamWaitEvent(g_dev.copy_stream, g_dev.rendered[set], 0));
+        uint8_t* dst = rgb8_out + static_cast<size_t>(f) * frame_bytes;
+        const size_t bytes = frame_bytes * static_cast<size_t>(nb);
+        if (direct) {
+            HIP_TRY(copy_out(dst, scene->d_batch[set], bytes, g_dev.copy_stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(g_dev.staging[set], scene->d_batch[set], bytes, hipMemcpyDeviceToHost, g_dev.copy_stream));
+            pending[set] = Pending{dst, bytes};
+        }
+        HIP_TRY(hipEventRecord(g_dev.copied[set], g_dev.copy_stream));
+        if (!direct) HIP_TRY(drain(set ^ 1));   // the batch before this one: its copy ran while this one was enqueued, the GPU renders on
+    }
+    if (!direct) { HIP_TRY(drain(0)); HIP_TRY(drain(1)); }
+    HIP_TRY(hipEventRecord(g_dev.ev1, g_dev.stream));
+    uint64_t counters[RT_N_COUNTERS] = {};
+    if (stats) HIP_TRY(hipMemcpyAsync(counters, g_dev.d_counters, sizeof(counters), hipMemcpyDeviceToHost, g_dev.stream));
+    HIP_TRY(hipStreamSynchronize(g_dev.stream));
+    HIP_TRY(hipStreamSynchronize(g_dev.copy_stream));
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_dev.ev0, g_dev.ev1));
+        *stats = RtStats{};
+        stats->rays = counters[0];
+        stats->rays_coincident = counters[7];
+        stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return RT_OK;

@@ -160,3 +160,42 @@ def test_more_than_a_third_of_2_31_pixels_per_call(gpu):
         finally:
             scene.close()
     assert e.value.code == rt.RT_ERR_LIMIT
+
+
+def test_render_frames_into_host_memory(gpu):
+    """rt_render_frames: F whole frames into host memory, frame f == rt_render with seed + f, for a frame that goes straight from
+    the shading kernel to the pixels (20000 ellipsoids; 5 frames = batches of 3 + 2) and one that queues rays and resolves
+    accumulators (default scene with shadows; 18 frames = batches of 16 + 2 through both staging sets), a reused buffer, and
+    the arguments it refuses."""
+    desc = workloads.bvh_stress_scene(20000, 640, 360)
+    scene = rt.Scene(desc)
+    p = workloads.default_config().params(rng="seeded", seed=5)
+    out = np.full((5, 360, 640, 3), 9, dtype=np.uint8)
+    for _ in range(2):   # the second call finds its buffer known
+        got, st = scene.render_frames(p, 5, out=out, stats=True)
+        assert got is out and st.rays == 5 * 640 * 360
+        q = p.copy()
+        for f in range(5):
+            q.seed = p.seed + f
+            assert np.array_equal(out[f], scene.render(q)), f
+        assert not np.array_equal(out[0], out[1])
+    part = p.copy()
+    part.tile_rows, part.part_index, part.part_count = 8, 0, 2
+    with pytest.raises(rt.RtError):
+        scene.render_frames(part, 2)
+    mega = p.copy()
+    mega.schedule = rt.RT_SCHEDULE_MEGAKERNEL
+    with pytest.raises(rt.RtError):
+        scene.render_frames(mega, 2)
+    with pytest.raises(rt.RtError):
+        scene.render_frames(p, 0, out=np.zeros((0, 360, 640, 3), dtype=np.uint8))
+    scene.close()
+    scene_file, params, golden = helpers.load_case("c1_shadows_fresnel")
+    scene = rt.Scene(scene_file)
+    one = scene.render(params)
+    many = scene.render_frames(params, 18)
+    scene.close()
+    assert helpers.diff_stats(one, golden)[0] <= 1
+    for f in range(18):   # deterministic sampling: every frame is the same picture up to the order of the FP64 additions
+        mx, nd, _ = helpers.diff_stats(many[f], one)
+        assert mx <= 1 and nd <= 0.002 * one.size, (f, mx, nd)
