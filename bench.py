@@ -50,6 +50,7 @@ from raytracer_amd import workloads  # noqa: E402
 from raytracer_amd.distributed import FrameGather, init_comm  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md, L2 (per XCD): 4 MiB per XCD, ~34.5 TB/s aggregate
 NODE_BYTES = 64           # one DNode4: four quantised child boxes + child references (device_types.h)
 SPHERE_BYTES_LAYOUT = 16 + 144   # what a sphere test really reads here: DPrim header + FP64 DXform (device_types.h)
 SPHERE_BYTES_SURVEY = 64         # SURVEY 8(d)'s constant (3x4 FP32 inverse affine + ids)
@@ -154,7 +155,23 @@ def spawn_ranks(n):
     return subprocess.call(cmd)
 
 
-def other_configs(dev):
+def config_cpu_baseline(scene_file, params, rays_per_frame, height):
+    """The oracle port on this host's cores on a row subset of the same frame (every k-th row, k chosen so that the sample is
+    about 4 x 10^7 rays: a few seconds), as a rate: rows are independent, so the rate of the sample is the rate of the frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    step = max(1, int(np.ceil(rays_per_frame / 4e7)))
+    try:
+        _, cnt = oracle_py.render(scene_file, params, threads=threads, counters=True, rows=(0, height, step))
+        secs = oracle_py.last_render_seconds()
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)[:200]}
+    return {"value": round(cnt[0] / secs / 1e6, 4), "unit": "Mrays/s", "cores": oracle_py.last_threads(), "kind": "port",
+            "sample": "every %d-th row of the same frame (%d rays, %.2f s on %d threads); pixel loop only" % (step, cnt[0], secs, oracle_py.last_threads())}
+
+
+def other_configs(dev, with_cpu=True):
     """The other BASELINE configs on this GPU (N = 1 only, after the headline): whole frames from the committed fixtures at the
     configs' sizes, scene resident, output in HBM; rays from an untimed counting pass.  The kernel that dominates each frame
     and its share come from the committed kernel traces (profiles/config_kernels.json), labelled as such."""
@@ -214,6 +231,7 @@ def other_configs(dev):
                 sc.close()
                 k = shares.get(name, {})
                 traced = int(st.rays) - int(st.rays_coincident)
+                cpu = config_cpu_baseline(sf, p, int(st.rays), h) if with_cpu else None
                 res.append({"config": label, "fixture": name, "resolution": [w, h], "spp": spp, "rays_per_frame": int(st.rays),
                             # rays as the reference counts them (its world.intersect calls); of these, the 2 x shadow_samples rays of a hit
                             # towards a light of radius 0 are one and the same ray, which is traced once: both counts, both rates
@@ -224,8 +242,20 @@ def other_configs(dev):
                             "ms_per_pass_in_rt_accumulate_device": round(ms_acc, 3) if ms_acc else None,
                             "dominant_kernel": k.get("kernel"), "dominant_kernel_fraction": k.get("fraction"),
                             "dominant_kernel_source": k.get("source")})
-                if k.get("valu"):   # VALU issue and lane fractions of the frame's kernels, from the committed PMC passes
-                    res[-1]["valu"] = k["valu"]
+                if cpu:
+                    cpu["gpu_over_cpu"] = round((st.rays / ms / 1e3) / cpu["value"], 1) if cpu["value"] > 0 else None
+                    res[-1]["cpu_baseline"] = cpu
+                if k.get("valu"):
+                    # SURVEY 8(d), small scenes: bound by VALU issue under divergence.  Roofline of the frame's kernels from the committed
+                    # PMC passes (instructions and active lanes are fixed by the build and the frame; the busy time was measured in the
+                    # same passes): achieved = VALU wave-instructions x 64 x active-lane fraction / GPU busy time, peak = 39.32 Tlane-op/s.
+                    v = k["valu"]
+                    res[-1]["roofline"] = {"bound": "valu", "kernel": k.get("kernel"), "unit": "Tlane-op/s", "peak": round(VALU_PEAK_TLANEOPS, 2),
+                                           "achieved": round(v["issue_fraction"] * v["active_lane_fraction"] * VALU_PEAK_TLANEOPS, 3),
+                                           "frac": round(v["issue_fraction"] * v["active_lane_fraction"], 4),
+                                           "issue_fraction": v["issue_fraction"], "active_lane_fraction": v["active_lane_fraction"],
+                                           "kernels": v.get("kernels"), "run": v.get("run"), "traffic": v.get("hbm_bytes_per_frame"),
+                                           "pmc_source": v.get("source")}
             except Exception as e:   # the headline does not depend on these
                 res.append({"config": label, "fixture": name, "error": str(e)[:200]})
         rt.release_workspaces()
@@ -561,6 +591,10 @@ def main():
                 "kernel_ms_in_flight": round(traverse_ms_in_flight, 4), "kernel_launches_in_flight": launches,
                 "kernel_ms_one_frame_per_launch": round(traverse_ms_one_frame, 4) if traverse_ms_one_frame else None,
                 "unit": "Tlane-op/s", "peak": round(VALU_PEAK_TLANEOPS, 2), "achieved": None, "frac": None, "traffic": None,
+                # SURVEY 8(d)'s own figure next to the utilisation: the ALGORITHMIC flops (22 per box test + 60 per sphere test) over
+                # the kernel time against the FP32 vector peak.  `frac` counts every instruction the kernel issues as useful (sorting,
+                # pushing and scheduling included); this one only the arithmetic the survey's formula prices.
+                "frac_algorithmic": round(alg_flops / kt / 1e12 / VALU_PEAK_FP32_TFLOPS, 5) if kt > 0 else None,
                 "algorithmic": {"flops_per_launch": alg_flops, "TFLOP_per_s": round(alg_flops / kt / 1e12, 3) if kt > 0 else None,
                                 "frac_of_fp32_vector_peak": round(alg_flops / kt / 1e12 / VALU_PEAK_FP32_TFLOPS, 5) if kt > 0 else None,
                                 "flops_per_ray": "22*box_tests + 60*sphere_tests (SURVEY 8(d))"},
@@ -580,6 +614,11 @@ def main():
             roof["hbm"] = {"GB_per_s_measured": round(pmc["hbm_bytes_per_launch"] / kt / 1e9, 1) if pmc.get("hbm_bytes_per_launch") else None,
                            "frac_of_peak": round(pmc["hbm_bytes_per_launch"] / kt / 1e9 / HBM_PEAK_GBS, 4) if pmc.get("hbm_bytes_per_launch") else None,
                            "l2_hit_rate": pmc.get("l2_hit_rate")}
+            if pmc.get("l2_request_bytes_per_launch"):
+                # the memory level the node array lives in: requests the XCDs' L2s served (128 B each), against their 34.5 TB/s aggregate
+                l2 = pmc["l2_request_bytes_per_launch"] / kt / 1e9
+                roof["l2"] = {"GB_per_s": round(l2, 1), "peak_GB_per_s": L2_PEAK_GBS, "frac": round(l2 / L2_PEAK_GBS, 4),
+                              "bytes_per_launch": pmc["l2_request_bytes_per_launch"], "hit_rate": pmc.get("l2_hit_rate")}
             roof["pmc_source"] = {"file": "profiles/pmc_c2.json", "build": pmc.get("build"), "collected": pmc.get("collected"),
                                   "note": "counter totals per launch come from that file (separate rocprofv3 --pmc passes); only the durations are measured in this run"}
         out = {
@@ -617,7 +656,7 @@ def main():
         if world == 1 and not args.no_configs:
             scene.close()
             rt.release_workspaces()
-            out["configs"] = other_configs(dev)
+            out["configs"] = other_configs(dev, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

@@ -767,6 +767,23 @@ __device__ __forceinline__ int node4_step(const NodeRegs& n, const RayF& f, floa
     float e[4];
     node4_test(n, f, tmin, tmax, e);
     int c[4] = {n.child[0], n.child[1], n.child[2], n.child[3]};
+#ifdef RT_NO_CHILD_SORT
+    // Experiment (what the ordering is worth): the nearest entered child is still taken first, but the other entered
+    // children are deferred in SLOT order instead of sorted by entry distance -- no 5-comparator network, no compaction of the
+    // misses, three conditional pushes.  Same closest hit (order independent); the entry distances still cull at pop time.
+    {
+        const float m = fminf(fminf(e[0], e[1]), fminf(e[2], e[3]));
+        if (m == INFINITY) return POP ? stack.pop(sp, tmax) : kNoChild;
+        const int k = e[0] == m ? 0 : e[1] == m ? 1 : e[2] == m ? 2 : 3;
+        int first = c[0];
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            if (j == k) first = c[j];
+            else if (e[j] != INFINITY) stack.push(sp, c[j], e[j]);
+        }
+        return first;
+    }
+#endif
 #define RT_CSWAP(i, j)                                                      \
     {                                                                       \
         const bool sw = e[j] < e[i];                                        \

@@ -46,6 +46,13 @@ struct WavefrontWorkspace {
     // its own, driven by a second host thread, into the same accumulators (see launch_render_wavefront).
     WavefrontWorkspace* partner = nullptr;
     hipStream_t partner_stream = nullptr;
+    // History order of the primary-ray queue's chunks (render_wavefront.hip: k_chunk_order): per chunk of 64 rays the most node
+    // steps of one of its rays in the last launch over such a queue, and the order (longest first) the next one hands them out in.
+    unsigned* chunk_cost = nullptr;
+    unsigned* chunk_order = nullptr;
+    size_t chunk_capacity = 0;           // chunks both arrays hold
+    unsigned long long chunk_key[4] = {0, 0, 0, 0};   // scene, queue size and frame layout the record belongs to
+    bool chunk_order_valid = false;
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);
 

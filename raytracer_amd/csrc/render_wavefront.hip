@@ -449,13 +449,51 @@ __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
     return q >= kXcds ? n : (unsigned)(((unsigned long long)n * q / kXcds) & ~63ull);
 }
 
+// History order of a queue's chunks.  A launch of the persistent kernel ends with a tail: the last rays to START include long
+// ones (the longest ray of the 10^6-ellipsoid frame takes 361 node steps against a mean of 47), and while they finish most of
+// the machine idles -- 0.4 of the 1.0 ms of a one-frame launch.  Which rays are long cannot be known in advance, but frames of a
+// sequence resemble each other: k_traverse records per chunk (64 rays = one 8x8 tile) the most node steps one of its rays took,
+// when that is well above the mean, and k_chunk_order turns the record into the order in which every XCD's share hands out
+// its chunks next time -- longest first (counting sort into 32 buckets by step count; order inside a bucket as recorded).
+// Scheduling only: every ray is traced exactly as before.  The record belongs to the workspace of a stream and is used only
+// for a queue of the same scene, size and frame layout (Driver::chunk_history).
+#ifndef RT_LONG_RAY_STEPS
+#define RT_LONG_RAY_STEPS 64      // (48 .. 64 measure alike, 96 and 128 worse: one-frame launch 0.826 / 0.837 / 0.871 ms)
+#endif
+#ifndef RT_ORDER_BUCKET_SHIFT
+#define RT_ORDER_BUCKET_SHIFT 3   // buckets of 8 steps
+#endif
+constexpr unsigned kLongRaySteps = RT_LONG_RAY_STEPS;
+constexpr unsigned kOrderBuckets = 32;
+__global__ void __launch_bounds__(kBlock) k_chunk_order(unsigned* __restrict__ cost, unsigned* __restrict__ order, const unsigned n_rays) {
+    __shared__ unsigned hist[kOrderBuckets], offset[kOrderBuckets];
+    const unsigned q = blockIdx.x;                                   // one workgroup per XCD share of the queue
+    const unsigned lo = share_begin(n_rays, q) / (unsigned)RT_CHUNK, hi = share_begin(n_rays, q + 1u) / (unsigned)RT_CHUNK;
+    if (threadIdx.x < kOrderBuckets) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    // bucket 0 holds the longest (steps >= 64 + 30 * 8), the last bucket the chunks without a long ray
+    auto bucket_of = [](unsigned c) { return c < kLongRaySteps ? kOrderBuckets - 1u : (kOrderBuckets - 2u) - min(kOrderBuckets - 2u, (c - kLongRaySteps) >> RT_ORDER_BUCKET_SHIFT); };
+    for (unsigned i = lo + threadIdx.x; i < hi; i += kBlock) atomicAdd(&hist[bucket_of(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (unsigned b = 0; b < kOrderBuckets; ++b) { offset[b] = run; run += hist[b]; }
+    }
+    __syncthreads();
+    for (unsigned i = lo + threadIdx.x; i < hi; i += kBlock) {
+        order[lo + atomicAdd(&offset[bucket_of(cost[i])], 1u)] = i;
+        cost[i] = 0u;                                                // the next launch records anew
+    }
+}
+
 // COUNT: also count box tests / node fetches / primitive tests (the statistics pass of bench.py and RtStats); the
 // timed variant carries neither the registers nor the instructions for them.
 template <int F, bool COUNT>
 __global__ void __launch_bounds__(kBlock, traverse_waves<F>())
 k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, const unsigned n_host,
            const unsigned* __restrict__ n_device, const unsigned rays_per_block, unsigned* __restrict__ next,
-           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total) {
+           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total,
+           const unsigned* __restrict__ chunk_order, unsigned* __restrict__ chunk_cost) {
     __shared__ unsigned long long stack_mem[kTravLdsEntries + 1][kBlock];   // + 1: the row branch-free pushes discard into
     // n_device != NULL: the queue was filled by the shading kernel launched before this one and the host has not read
     // its size (levels enqueued without a round trip); n_host is then the queue's capacity, which a count that
@@ -476,6 +514,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
     bool exhausted = false;
     unsigned my = kNone;                               // queue index of this lane's ray; kNone = idle lane
     unsigned chunk_next = 0, chunk_end = 0;            // this wave's reserved rays [chunk_next, chunk_end)
+    unsigned steps = 0;                                // node steps of this lane's ray (what chunk_cost records)
     const unsigned xcd = blockIdx.x & (kXcds - 1u);     // workgroups are dealt to the XCDs round-robin
     unsigned victim = 0;                               // shares of the queue found empty so far
     constexpr bool kFp32 = (F & RT_FEAT_FP32) != 0;   // the throughput variant: FP32 sphere test (test_sphere32), the ray kept in FP32
@@ -507,6 +546,13 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 if (base < hi - lo) {
                     chunk_next = lo + base;
                     chunk_end = (hi - lo - base < (unsigned)RT_CHUNK) ? hi : chunk_next + (unsigned)RT_CHUNK;
+                    // History order (k_chunk_order): the c-th chunk a share hands out is the one that held the longest rays when
+                    // this queue was last traced, so the rays started last are the short ones and the launch ends without
+                    // a tail of long rays started late.  (Only whole chunks: the host passes an order when n is a multiple of RT_CHUNK.)
+                    if (chunk_order) {
+                        chunk_next = chunk_order[chunk_next / (unsigned)RT_CHUNK] * (unsigned)RT_CHUNK;
+                        chunk_end = chunk_next + (unsigned)RT_CHUNK;
+                    }
                 } else if (++victim == kXcds) {
                     exhausted = true;
                     break;
@@ -532,6 +578,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
                 sp = 0;
                 cur = kDone;
                 pend = 0;
+                steps = 0;
                 if (S.n_prims > 0) {
                     if (P.use_bvh) {
                         rf = make_rayf(r);
@@ -580,6 +627,7 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
 #endif
                 if (is_node) {
                     const NodeRegs nd = load_node(&S.nodes[cur]);
+                    ++steps;
                     if (COUNT) { C.nodes += node4_children(nd); C.visits++; ray_visits++; }
                     cur = node4_step<false>(nd, rf, tmin32, tmax32, stack, sp);
                     // one pop loop per step for both kinds of lanes that need their next deferred node: no child entered, or
@@ -616,6 +664,8 @@ k_traverse(const DScene S, const DParams P, const RayQ rays, const HitQ hits, co
             HitRec h;
             h.t = best.t; h.bu = best.bu; h.bv = best.bv; h.prim = best.prim; h.tri = best.tri;
             hit_store(hits, my, h);
+            // a ray that took more than the mean number of node steps (~47 on the 10^6-ellipsoid frame) marks its chunk as a long one
+            if (chunk_cost && steps >= kLongRaySteps) atomicMax(&chunk_cost[my / (unsigned)RT_CHUNK], steps);
             my = kNone;
             if (COUNT) { max_visits = max(max_visits, ray_visits); ray_visits = 0; }
         }
@@ -1357,12 +1407,52 @@ struct Driver {
         const unsigned per_block = kBlock * (unsigned)std::max(1, ws.rays_per_lane);
         const unsigned want = (n + per_block - 1) / per_block;
         const unsigned blocks = std::max(1u, std::min((unsigned)traverse_blocks, want));
+        const unsigned *order = nullptr;
+        unsigned* cost = nullptr;
+        const bool history = chunk_history(n, n_device != nullptr, level, &order, &cost);
         if (P.count_tests)
             hipLaunchKernelGGL((k_traverse<F, true>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), n, n_device, per_block,
-                               ws.counters + kNextBase, ws.stats, level_total);
+                               ws.counters + kNextBase, ws.stats, level_total, order, cost);
         else
             hipLaunchKernelGGL((k_traverse<F, false>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), n, n_device, per_block,
-                               ws.counters + kNextBase, ws.stats, level_total);
+                               ws.counters + kNextBase, ws.stats, level_total, order, cost);
+        if (history) {   // this launch's record -> the order of the next launch over such a queue
+            hipLaunchKernelGGL(k_chunk_order, dim3(kXcds), dim3(kBlock), 0, stream, ws.chunk_cost, ws.chunk_order, n);
+            ws.chunk_order_valid = true;
+        }
+    }
+    // The chunk history of this stream (see k_chunk_order): kept for primary-ray queues of whole frames -- the level-0 queue of a
+    // launch that is one chunk -- of one scene, size and frame layout at a time.  *order: the order recorded by the previous such
+    // launch, or null (none yet, another queue since, RT_NO_CHUNK_ORDER); *cost: where this launch records.
+    bool chunk_history(unsigned n, bool size_on_device, int level, const unsigned** order, unsigned** cost) {
+        static const bool off = getenv("RT_NO_CHUNK_ORDER") != nullptr;
+        if (off || ws.fixed || level != 0 || size_on_device || n < 65536u || n % (unsigned)RT_CHUNK != 0u) return false;
+        if ((long long)chunk.rows * P.width * chunk.ns != (long long)n || chunk.rows != P.frames * P.part_rows || chunk.ns != P.spp) return false;   // not the whole launch
+        const unsigned chunks = n / (unsigned)RT_CHUNK;
+        const unsigned long long key[4] = {S.serial, ((unsigned long long)n << 32) | (unsigned)P.frames, ((unsigned long long)P.part_index << 32) | (unsigned)P.part_count,
+                                           ((unsigned long long)P.width << 32) | (unsigned)P.part_rows};
+        if (ws.chunk_capacity < chunks) {
+            if (ws.chunk_cost) { if (!ok(hipStreamSynchronize(stream))) return false; (void)hipFree(ws.chunk_cost); (void)hipFree(ws.chunk_order); }
+            ws.chunk_cost = ws.chunk_order = nullptr;
+            ws.chunk_capacity = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&ws.chunk_cost), chunks * sizeof(unsigned)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&ws.chunk_order), chunks * sizeof(unsigned)) != hipSuccess) {
+                (void)hipGetLastError();
+                if (ws.chunk_cost) (void)hipFree(ws.chunk_cost);
+                ws.chunk_cost = ws.chunk_order = nullptr;
+                return false;   // no history: the launch runs in queue order
+            }
+            ws.chunk_capacity = chunks;
+            ws.chunk_order_valid = false;
+        }
+        if (!ws.chunk_order_valid || memcmp(key, ws.chunk_key, sizeof(key)) != 0) {
+            if (!ok(hipMemsetAsync(ws.chunk_cost, 0, chunks * sizeof(unsigned), stream))) return false;
+            memcpy(ws.chunk_key, key, sizeof(key));
+            ws.chunk_order_valid = false;
+        }
+        *order = ws.chunk_order_valid ? ws.chunk_order : nullptr;
+        *cost = ws.chunk_cost;
+        return true;
     }
     unsigned *zero_a = nullptr, *zero_b = nullptr;   // tails the next small-scene traversal launch zeroes (run_levels)
     bool allow_grow = true;   // a frame of one chunk whose ray tree outgrows the queues gets larger queues next time (a frame of
@@ -1581,6 +1671,8 @@ void wavefront_workspace_free(WavefrontWorkspace& ws) {
         if (ws.counters) (void)hipFree(ws.counters);
         if (ws.shard_counts) (void)hipFree(ws.shard_counts);
         if (ws.stats) (void)hipFree(ws.stats);
+        if (ws.chunk_cost) (void)hipFree(ws.chunk_cost);
+        if (ws.chunk_order) (void)hipFree(ws.chunk_order);
     }
     for (hipEvent_t e : ws.events) (void)hipEventDestroy(e);
     ws = WavefrontWorkspace();

@@ -336,3 +336,38 @@ def test_queues_outlive_scenes_and_can_be_reserved(gpu):
     scene = rt.Scene(scene_file)
     assert helpers.diff_stats(scene.render(params), golden)[0] <= 1   # allocates again
     scene.close()
+
+
+def test_history_order_of_the_chunks_changes_no_pixel(gpu):
+    """k_traverse hands out the chunks of a primary-ray queue longest-first, by what the previous launch over such a queue
+    recorded (k_chunk_order): scheduling only.  The first frame of a scene on a fresh stream has no history, the following ones
+    do; single frames and launches of several frames, deterministic and seeded: all equal to the first / to the frames rendered
+    one by one, and to the megakernel, which has no queue at all."""
+    dev = torch.device("cuda", 0)
+    sd = workloads.bvh_stress_scene(200_000, 1920, 1080)
+    scene = rt.Scene(sd)
+    p = workloads.default_config().params(rng="d0")
+    stream = torch.cuda.Stream(dev)
+    bufs = [torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+    torch.cuda.synchronize(dev)
+    for b in bufs:
+        scene.render_device(p, b.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+    pm = p.copy()
+    pm.schedule = rt.RT_SCHEDULE_MEGAKERNEL
+    mega = scene.render(pm)
+    assert mega.any()
+    for b in bufs:
+        assert np.array_equal(b.cpu().numpy(), mega)
+    ps = workloads.default_config().params(rng="seeded", seed=40)
+    many = torch.zeros((3, 4, 1080, 1920, 3), dtype=torch.uint8, device=dev)
+    for k in range(3):   # the same four frames three times: the second and third launch follow the first one's record
+        scene.render_frames_device(ps, 4, many[k].data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+    assert torch.equal(many[0], many[1]) and torch.equal(many[0], many[2])
+    q = ps.copy()
+    for f in range(4):
+        q.seed = ps.seed + f
+        q.schedule = rt.RT_SCHEDULE_MEGAKERNEL
+        assert np.array_equal(many[2, f].cpu().numpy(), scene.render(q)), f
+    scene.close()
