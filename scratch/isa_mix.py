@@ -3,7 +3,7 @@
 import collections, re, subprocess, sys
 path, wants = sys.argv[1], sys.argv[2:]
 txt = open(path).read()
-for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", txt, re.S | re.M):
+for m in re.finditer(r"^((?:_Z|k_)\w+):[^\n]*\n(.*?)^\.Lfunc_end", txt, re.S | re.M):
     name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
     name = re.sub(r"^void rt::\(anonymous namespace\)::", "", name); name = re.sub(r"\(.*", "", name)
     if wants and not any(w in name for w in wants): continue
