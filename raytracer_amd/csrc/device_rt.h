@@ -80,29 +80,46 @@ struct Rng {
         return z ^ (z >> 31);
     }
     __device__ __forceinline__ double uniform() { return d0 ? 0.5 : (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
-    // random_utils.h:29-35 (rejection sampling of the unit ball).  A wave repeats the loop until its unluckiest lane has
-    // accepted (6-8 rounds at 52 % acceptance), so a round is kept cheap: ONE draw gives the three coordinates, 21 bits
-    // each, tested in FP32 (the values are exact there); the distribution is the reference's up to that resolution.
+    // A direction uniform on the unit sphere from 42 bits of one draw: height z = 1 - 2u (uniform by Archimedes), azimuth 2 pi v,
+    // in FP32 (v_sin_f32 / v_cos_f32 take their argument in revolutions).
+    static __device__ __forceinline__ void unit_direction(unsigned long long z, float& x, float& y, float& w) {
+        const float u = ((float)(unsigned)(z & 0x1FFFFFull) + 0.5f) * (1.0f / 2097152.0f);
+        const float v = ((float)(unsigned)((z >> 21) & 0x1FFFFFull) + 0.5f) * (1.0f / 2097152.0f);
+        w = 1.0f - 2.0f * u;
+        const float s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - w * w));
+        x = s * __builtin_amdgcn_cosf(v);
+        y = s * __builtin_amdgcn_sinf(v);
+    }
+    // random_utils.h:29-35: a point uniform in the unit ball.  The reference rejects points of the cube; a wave would repeat
+    // such a loop until its unluckiest lane has accepted (6-8 rounds at 52 % acceptance, each with the generator's two 64-bit
+    // multiplies), so the same distribution is drawn directly instead: a uniform direction times a radius u^(1/3), from ONE
+    // draw (21 + 21 + 22 bits), in FP32.  The deterministic mode returns the centre, as the oracle's shim does.
     __device__ D3 in_unit_sphere() {
         if (d0) return mk(0, 0, 0);
-        for (int it = 0; it < 64; ++it) {  // 64 tries leave 1e-21 of the mass
-            const unsigned long long z = next();
-            const float x = ((float)(unsigned)(z & 0x1FFFFFull) + 0.5f) * (1.0f / 1048576.0f) - 1.0f;
-            const float y = ((float)(unsigned)((z >> 21) & 0x1FFFFFull) + 0.5f) * (1.0f / 1048576.0f) - 1.0f;
-            const float w = ((float)(unsigned)((z >> 42) & 0x1FFFFFull) + 0.5f) * (1.0f / 1048576.0f) - 1.0f;
-            if (x * x + y * y + w * w < 1.0f) return mk((double)x, (double)y, (double)w);
-        }
-        return mk(0, 0, 0);
+        const unsigned long long z = next();
+        float x, y, w;
+        unit_direction(z, x, y, w);
+        const float t = ((float)(unsigned)(z >> 42) + 0.5f) * (1.0f / 4194304.0f);
+        const float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(t) * (1.0f / 3.0f));
+        return mk((double)(r * x), (double)(r * y), (double)(r * w));
     }
-    // camera.cpp:13-24 (rejection sampling of the unit disk; the reference's rand() has 31 bits, these have 32)
+    // random_in_unit_sphere().normalize() (shading.h:35): a direction uniform on the sphere, which is what normalising a uniform
+    // point of the ball gives; unit length to FP32 rounding.  Deterministic mode: the zero vector (vector3.h:92-102 on the centre).
+    __device__ D3 on_unit_sphere() {
+        if (d0) return mk(0, 0, 0);
+        float x, y, w;
+        unit_direction(next(), x, y, w);
+        return mk((double)x, (double)y, (double)w);
+    }
+    // camera.cpp:13-24: a point uniform in the unit disk (the reference rejects points of the square), drawn directly like the
+    // ball's: radius sqrt(u), azimuth 2 pi v, 24 bits of one draw each, FP32.
     __device__ D3 in_unit_disk() {
         if (d0) return mk(0, 0, 0);
-        for (int it = 0; it < 64; ++it) {
-            const unsigned long long z = next();
-            D3 p = mk(((double)(unsigned)(z >> 32) + 0.5) * (1.0 / 2147483648.0) - 1.0, ((double)(unsigned)z + 0.5) * (1.0 / 2147483648.0) - 1.0, 0.0);
-            if (dot(p, p) < 1.0) return p;
-        }
-        return mk(0, 0, 0);
+        const unsigned long long z = next();
+        const float u = ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+        const float v = ((float)(unsigned)(z & 0xFFFFFFull) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = __builtin_amdgcn_sqrtf(u);
+        return mk((double)(r * __builtin_amdgcn_cosf(v)), (double)(r * __builtin_amdgcn_sinf(v)), 0.0);
     }
 };
 

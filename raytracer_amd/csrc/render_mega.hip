@@ -54,7 +54,7 @@ __device__ D3 light_visibility(const DScene& S, const DParams& P, const DLight& 
     D3 acc = mk(0, 0, 0);
     for (int i = 0; i < P.shadow_samples; ++i) {
         D3 lp = ld3(L.pos);
-        if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
+        if (L.radius != 0.0) lp = lp + rng.on_unit_sphere() * L.radius;  // shading.h:31-36
         D3 d = lp - Pt;
         double dist = length(d);
         d = normalize(d);

@@ -843,9 +843,11 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
             wr = wr * (1.0 / samples);
             Rng dry = rng_e;
             for (int k = 0; k < samples; ++k) {
-                D3 off = dry.in_unit_sphere() * rough;
-                D3 target = normalize(perfect + off);
-                if (dot(target, h.n) > 0) { keep |= 1ull << k; (void)dry.next(); }
+                // (tracer.h:197-199 tests the NORMALISED direction; its sign is the unnormalised one's unless the vector is shorter
+                // than vector3.h's 1e-6.  The deterministic mode keeps the reference's form to the letter.)
+                const D3 v = perfect + dry.in_unit_sphere() * rough;
+                const bool above = dry.d0 ? dot(normalize(v), h.n) > 0 : (dot(v, h.n) > 0 && dot(v, v) > 1e-12);
+                if (above) { keep |= 1ull << k; (void)dry.next(); }
             }
         } else {
             keep = 1ull;
@@ -867,15 +869,11 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         const unsigned long long mk_ = __ballot((keep >> k) & 1ull);
         if (k < kmax) {
             D3 target = perfect;
-            bool mine_k = true;
-            if (samples > 0) {
-                D3 off = rng_e.in_unit_sphere() * rough;
-                target = normalize(perfect + off);
-                mine_k = dot(target, h.n) > 0;
-            }
+            const bool mine_k = (keep >> k) & 1ull;   // as the dry pass decided
+            if (samples > 0) target = perfect + rng_e.in_unit_sphere() * rough;
             if (mine_k)
-                emit_ray_at(E.out, slot0 + (unsigned)__popcll(mk_ & below), E.cap, E.overflow, org, target, wr, q.time, 100000.0, rng_e.next(), q.pixel,
-                            child_depth, kKindRadiance);
+                emit_ray_at(E.out, slot0 + (unsigned)__popcll(mk_ & below), E.cap, E.overflow, org, samples > 0 ? normalize(target) : target, wr, q.time,
+                            100000.0, rng_e.next(), q.pixel, child_depth, kKindRadiance);
         }
         slot0 += (unsigned)__popcll(mk_);
     }
@@ -923,7 +921,12 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         diff = diff * (1.0 - M.transparency);                                   // shading.h:166-167
         D3 Hv = normalize(Ld + V);
         double hdn = smax(0.0, dot(Hv, N));
-        D3 sp = cmul(ld3(M.specular), I) * exp(M.shininess * log(hdn));        // shading.h:206, fast_pow :177
+        // shading.h:206, fast_pow :177.  A material without a specular colour multiplies the power by zero: where the power is
+        // certain to be a finite number (0 <= hdn, 0 < shininess < inf: the exponent is -inf or finite) any finite factor gives
+        // the same product, bit for bit, and the two transcendental functions are left out (matte floors are most of the hits).
+        const bool matte = M.specular[0] == 0.0 && M.specular[1] == 0.0 && M.specular[2] == 0.0 && M.shininess > 0.0 && M.shininess < 1e300 && hdn >= 0.0;
+        const double power = matte ? 1.0 : exp(M.shininess * log(hdn));
+        D3 sp = cmul(ld3(M.specular), I) * power;
         if (!EMIT || !P.shadows) {  // visibility (1,1,1), shading.h:80
             ad = ad + cmul(diff, mk(1.0, 1.0, 1.0));
             spec = spec + cmul(sp, mk(1.0, 1.0, 1.0));
@@ -1087,7 +1090,7 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
             (void)rng.next();
             const D3 Pt = ld3(b.p);
             D3 lp = ld3(L.pos);
-            if (L.radius != 0.0) lp = lp + normalize(rng.in_unit_sphere()) * L.radius;  // shading.h:31-36
+            if (L.radius != 0.0) lp = lp + rng.on_unit_sphere() * L.radius;  // shading.h:31-36
             D3 d = lp - Pt;
             dist = length(d);
             d = normalize(d);

@@ -10,7 +10,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rt.init(0)
 dev = torch.device("cuda", 0)
 scene = rt.Scene(workloads.bvh_stress_scene(1_000_000, 1920, 1080))
-p = workloads.default_config().params(rng="d0")
+p = workloads.default_config().params(rng=os.environ.get("RT_BATCH_RNG", "seeded"), seed=12345)   # the sampling of bench.py's timed region
 if os.environ.get("RT_BATCH_SCHEDULE") == "fp32":   # the throughput variant
     p.schedule = rt.RT_SCHEDULE_WAVEFRONT_FP32
 buf = torch.zeros((F, 1080, 1920, 3), dtype=torch.uint8, device=dev)

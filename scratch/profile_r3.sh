@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=16 RT_RAYS_PER_LANE=8
 B="python3 bench.py --no-cpu-baseline --no-configs"
 # 1. kernel traces of the headline: one frame per launch, the default run, nothing but launches of 16 frames
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1 -- $B --steps 20 --warmup 2 --frames-in-flight 1 > $out/bench_1inflight.json 2> $out/bench_1inflight.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1 -- python3 scratch/batch_launches.py 1 > $out/batch1.txt 2> $out/batch1.err || exit 1
 cp $(find $out/trace1 -name "*kernel_stats.csv" | head -1) $out/c2_kernel_stats_1inflight.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace8 -- $B > $out/bench_default.json 2> $out/bench_default.err || exit 1
 cp $(find $out/trace8 -name "*kernel_stats.csv" | head -1) $out/c2_kernel_stats_default.csv
@@ -17,7 +17,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t
 cp $(find $out/traceb -name "*kernel_stats.csv" | head -1) $out/c2_kernel_stats_batch16.csv
 echo "traces done"
 # 2. PMC passes over the headline (each pass its own run, within the per-block counter limits): one frame per launch, then launches of 16
-pass() { name=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -- $B --steps 2 --warmup 1 --frames-in-flight 1 > /dev/null 2> $out/pmc_$name.err || return 1; }
+pass() { name=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -- python3 scratch/batch_launches.py 1 > /dev/null 2> $out/pmc_$name.err || return 1; }
 bpass() { name=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/pmcb_$name -- python3 scratch/batch_launches.py 16 > /dev/null 2> $out/pmcb_$name.err || return 1; }
 for p in pass bpass; do
   $p sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY || exit 1

@@ -8,7 +8,7 @@ src = "gpurun_out/prof_%s" % tag
 build = os.environ.get("RT_BUILD_ID") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 dst = os.environ.get("RT_PROFILE_OUT", "profiles")
 os.makedirs(dst, exist_ok=True)
-for f in ("c2_kernel_stats_1inflight.csv", "c2_kernel_stats_default.csv", "c2_kernel_stats_batch16.csv", "bench_1inflight.json", "bench_default.json", "batch16.txt"):
+for f in ("c2_kernel_stats_1inflight.csv", "c2_kernel_stats_default.csv", "c2_kernel_stats_batch16.csv", "batch1.txt", "bench_default.json", "batch16.txt"):
     shutil.copy(os.path.join(src, f), "%s/%s_%s" % (dst, rnd, f))
 
 def kname(k):
@@ -26,7 +26,7 @@ def pmc(prefix):
 
 c2 = pmc("pmc")
 with open("%s/%s_c2_pmc_summary.txt" % (dst, rnd), "w") as o:
-    o.write("# rocprofv3 --pmc, one pass per run (scratch/profile_r2.sh), bench.py --frames-in-flight 1, build %s\n" % build)
+    o.write("# rocprofv3 --pmc, one pass per run (scratch/profile_r3.sh), scratch/batch_launches.py 1 (one C2 frame per launch), build %s\n" % build)
     for k in c2:
         o.write("[%s] mean per launch over %d launches\n" % (k, len(next(iter(c2[k].values())))))
         for c, v in sorted(c2[k].items()):
