@@ -324,19 +324,25 @@ __device__ __forceinline__ void emit_ray_at(const RayQ out, unsigned slot, unsig
 
 // ------------------------------------------------------------------------------------------ k_raygen
 // Linear index -> pixel of the chunk, in 8-row bands of 8-wide tiles, so that 64 consecutive rays form an 8x8 tile.
-__device__ __forceinline__ void pixel_of(long long pix, int W, int rows, int& x, int& ly) {
+// (All of it in unsigned 32-bit arithmetic: a chunk holds fewer than 2^32 rays.  The divisors are the same for every lane and
+// mostly powers of two -- 8-wide tiles, 8-row bands and tiles, 1 or 16 frames, 1 sample -- which udiv_u settles with a shift behind
+// a scalar branch; the compiler's 64-bit division by a run-time number is some ninety instructions, and this runs once per
+// primary ray in k_raygen and once more in the kernel that shades it.)
+__device__ __forceinline__ unsigned udiv_u(unsigned a, unsigned d) { return (d & (d - 1u)) == 0u ? a >> __builtin_ctz(d) : a / d; }
+__device__ __forceinline__ void pixel_of(unsigned pix, int W, int rows, int& x, int& ly) {
     const int nb = (rows + 7) / 8;
-    int b = (int)(pix / ((long long)W * 8));
+    int b = (int)udiv_u(pix, (unsigned)W * 8u);
     if (b > nb - 1) b = nb - 1;
     const int hb = (b == nb - 1) ? rows - 8 * b : 8;
-    int j = (int)(pix - (long long)b * W * 8);
+    const int j = (int)(pix - (unsigned)b * (unsigned)W * 8u);
     const int tiles_x = (W + 7) / 8;
-    int tx = j / (8 * hb);
+    int tx = hb == 8 ? j >> 6 : j / (8 * hb);
     if (tx > tiles_x - 1) tx = tiles_x - 1;
     const int rem = j - tx * 8 * hb;
     const int tw = (8 * tx + 8 <= W) ? 8 : W - 8 * tx;
-    ly = b * 8 + rem / tw;
-    x = tx * 8 + rem % tw;
+    const int q = tw == 8 ? rem >> 3 : rem / tw;
+    ly = b * 8 + q;
+    x = tx * 8 + (rem - q * tw);
 }
 
 // Index i of a chunk's primary rays -> pixel (x, y) of the frame, sample, frame of the launch, and the pixel's index in the
@@ -345,25 +351,27 @@ __device__ __forceinline__ void pixel_of(long long pix, int W, int rows, int& x,
 // waves of one XCD traverse -- covers the same region of the image in all frames; parts whose rows are no multiple of 8 go
 // frame by frame.
 struct PrimaryCoords { int x, y, s, frame, pixel; };
-__device__ __forceinline__ PrimaryCoords primary_coords(const DParams& P, const Chunk& ck, long long i) {
+__device__ __forceinline__ PrimaryCoords primary_coords(const DParams& P, const Chunk& ck, unsigned i) {
     PrimaryCoords c;
-    const long long pix = i / ck.ns;
-    c.s = ck.s0 + (int)(i % ck.ns);
+    const unsigned pix = udiv_u(i, (unsigned)ck.ns);
+    c.s = ck.s0 + (int)(i - pix * (unsigned)ck.ns);
     int ly;
     pixel_of(pix, P.width, ck.rows, c.x, ly);
     int lr = ck.row0 + ly;
     c.frame = 0;
     if (P.frames > 1) {
         if ((P.part_rows & 7) == 0) {
-            const int band = lr >> 3;
-            c.frame = band % P.frames;
-            lr = (band / P.frames) * 8 + (lr & 7);
+            const unsigned band = (unsigned)lr >> 3;
+            const unsigned fb = udiv_u(band, (unsigned)P.frames);
+            c.frame = (int)(band - fb * (unsigned)P.frames);
+            lr = (int)fb * 8 + (lr & 7);
         } else {
-            c.frame = lr / P.part_rows;
+            c.frame = (int)udiv_u((unsigned)lr, (unsigned)P.part_rows);
             lr -= c.frame * P.part_rows;
         }
     }
-    c.y = ((lr / P.tile_rows) * P.part_count + P.part_index) * P.tile_rows + (lr % P.tile_rows);
+    const unsigned tile = udiv_u((unsigned)lr, (unsigned)P.tile_rows);
+    c.y = ((int)tile * P.part_count + P.part_index) * P.tile_rows + (lr - (int)tile * P.tile_rows);
     c.pixel = (c.frame * P.slice_rows + lr) * P.width + c.x;
     return c;
 }
@@ -371,7 +379,7 @@ __device__ __forceinline__ PrimaryCoords primary_coords(const DParams& P, const 
 __device__ __forceinline__ RayRec ray_load(const RayQ& q, unsigned i, const DParams& P) {
     if (!q.primary) return ray_load_full(q, i);
     RayRec r = ray_load_head(q, i);   // weight 1, radiance
-    r.pixel = primary_coords(P, q.ck, (long long)i).pixel;
+    r.pixel = primary_coords(P, q.ck, i).pixel;
     r.depth = (short)P.max_depth;
     return r;
 }
@@ -1049,6 +1057,7 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
     const bool merge = P.trace_coincident == 0;
     point_lights_only = point_lights_only && merge;
     const unsigned per = point_lights_only ? 1u : per_ref;
+    const int per_shift = (per & (per - 1u)) == 0u ? __builtin_ctz(per) : -1;
     // this workgroup's shard of the bundles (block_span in 64-bit lanes: a bundle is `per` lanes)
     const unsigned shard = blockIdx.x % in.shards;
     const unsigned long long n = (unsigned long long)min(in.counts[shard * kCountStride], in.region) * per;
@@ -1076,7 +1085,12 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
         Rng rng{0ull, true};
         unsigned copies = 1u;   // rays of the reference this lane's ray stands for
         if (mine) {
-            const unsigned bi = (unsigned)(i / per), k = (unsigned)(i % per);
+            // (lane -> bundle and sample: `per` is 2 x shadow_samples, a power of two with the reference's defaults -- a 64-bit
+            // division by a run-time number is some ninety instructions, a sixth of this kernel's per ray when it was written so)
+            unsigned bi, k;
+            if (per_shift >= 0) { bi = (unsigned)(i >> per_shift); k = (unsigned)i & (per - 1u); }
+            else if (n <= 0xffffffffull) { bi = (unsigned)i / per; k = (unsigned)i - bi * per; }
+            else { bi = (unsigned)(i / per); k = (unsigned)(i % per); }
             b = bundle_load(bundles, bi);
             const DLight& L = S.lights[b.light];
             const bool specular = k >= (unsigned)P.shadow_samples;
