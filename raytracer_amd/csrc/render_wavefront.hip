@@ -1190,8 +1190,11 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
 // k_traverse for scenes of at most kSmallScenePrims primitives: one lane per queued ray, every primitive tested in step
 // by the whole wave (closest_hit_small).  The persistent scheduling of k_traverse -- refill, votes, parked leaves, a
 // stack -- buys nothing when there is no hierarchy to speak of, and costs most of the time of such frames.
+#ifndef RT_SMALL_WAVES
+#define RT_SMALL_WAVES 4
+#endif
 template <int F>
-__global__ void __launch_bounds__(kBlock, 4)
+__global__ void __launch_bounds__(kBlock, RT_SMALL_WAVES)
 k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const HitQ hits_all, const QIn in,
                  unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total, unsigned* __restrict__ zero_a,
                  unsigned* __restrict__ zero_b, const unsigned zero_shards) {
