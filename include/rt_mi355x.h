@@ -10,6 +10,9 @@
  * rt_last_error() then returns a thread-local description (the reference reports errors as C++ exceptions caught
  * in main, Code/main.cpp:562-565).  No ownership is transferred across the ABI: the library copies what it
  * needs during the call.  One host thread may call the rt_render / rt_scene functions on a given scene at a time.
+ * The calls that deliver frames into HOST memory (rt_render, rt_render_frames, rt_render_gathered) run on the library's own
+ * stream and staging buffers and serialise on a lock inside the library; the *_device calls render on the caller's streams
+ * and may overlap (one render at a time per stream).
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H
@@ -295,10 +298,11 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
  * are rendered in batches that share one set of launches (rt_render_frames_device) and the device -> host copy of a batch
  * overlaps the render of the next.  Wavefront schedule, whole frames (part_count <= 1).  stats (may be NULL): rays and device
  * time of all frames together.
- * Both rt_render and rt_render_frames register the caller's buffer with the driver the second time they see it (hipHostRegister;
- * a render loop passes the same buffer again and again; at most 8 ranges are kept, least recently used first out, all
- * released by rt_shutdown) so that the copy is one DMA instead of the runtime's staged pageable copy.  Environment
- * RT_HOST_REGISTER=always registers at first sight, =never not at all. */
+ * The copies go through pinned staging buffers the library owns; the caller's buffer is ordinary memory and is only written by
+ * the calling thread(s) before the call returns.  Opt-in, environment RT_HOST_REGISTER=second|always: rt_render and
+ * rt_render_frames register the caller's buffer with the driver instead (hipHostRegister, the second / first time they see it;
+ * at most 8 ranges, least recently used first out, all released by rt_shutdown), which makes the copy one DMA -- and obliges
+ * the caller to keep such a buffer allocated until rt_shutdown (a registration pins the pages behind the addresses). */
 int rt_render_frames(rt_scene_t scene, const RtRenderParams* params, int frames, uint8_t* rgb8_out, RtStats* stats);
 
 /* Same pixels, but into device memory and asynchronously on `hip_stream` (a hipStream_t with HIP's own meaning: NULL is

@@ -59,15 +59,21 @@ struct DeviceState {
     size_t staging_bytes = 0;
 };
 DeviceState g_dev;
+// rt_render, rt_render_frames and rt_render_gathered work on the library's own stream, events, counters and staging buffers: they
+// are synchronous calls and take this lock for their duration, so that threads rendering different scenes into host memory
+// queue up instead of sharing that state (the *_device entry points on streams of the caller's run concurrently).
+std::recursive_mutex g_host_render_mutex;
 
 // The caller's frame buffer is ordinary (pageable) host memory: `Image::m_pixel_data` is a std::vector (Image.h:46-47).  A
 // device -> host copy into pageable memory goes through the runtime's own staging buffers at a fraction of the link's rate
-// (6.2 MB of a 1080p frame: ~0.5 ms); into memory that is registered with the driver it is one DMA (~0.15 ms).  So the
-// buffers rt_render / rt_render_frames are handed are registered on first use and stay registered -- a render loop passes
-// the same buffer again and again -- up to kMaxPins of them (the least recently used one is unregistered), until
-// rt_shutdown.  Registration is by address range: a buffer that was freed and whose range is handed out again is simply
-// registered memory still (the driver follows the range, not the allocation); should a copy into a cached range ever fail,
-// the range is dropped and the copy repeated the pageable way.  RT_NO_HOST_REGISTER=1 turns the cache off.
+// (6.2 MB of a 1080p frame: ~0.5 ms); into memory that is registered with the driver it is one DMA (~0.15 ms).  By default the
+// library copies through pinned staging buffers of its own (DeviceState::staging) and never touches the caller's pages.
+// OPT-IN, RT_HOST_REGISTER=second|always: the buffers rt_render / rt_render_frames are handed are registered (on second / first
+// sight) and stay registered -- a render loop passes the same buffer again and again -- up to kMaxPins of them (the least
+// recently used one is unregistered), until rt_shutdown.  The contract that comes with it: a buffer handed to these calls must
+// not be freed while the library is initialised -- a registration pins the PHYSICAL pages behind the range, and a new allocation
+// that lands on the same addresses would not be what the DMA writes to.  That is why it is not the default.  Should a copy into a
+// cached range fail, the range is dropped and the copy repeated the pageable way.
 struct HostPin {
     uintptr_t base = 0;
     size_t bytes = 0;
@@ -97,14 +103,14 @@ void unpin(void* host) {
             return;
         }
 }
-// true: [host, host + bytes) is registered with the driver now.  A buffer is registered the SECOND time it is seen (a render
-// loop's buffer; registering costs about as much as one pageable copy, so a buffer that is used once is better off without);
-// RT_HOST_REGISTER=always registers at first sight, =never (or RT_NO_HOST_REGISTER=1) not at all.
+// true: [host, host + bytes) is registered with the driver now.  Off unless RT_HOST_REGISTER asks for it (see above): `second`
+// registers a buffer the SECOND time it is seen (registering costs about as much as one pageable copy, so a buffer that is used
+// once is better off without), `always` at first sight.
 bool pin_host(void* host, size_t bytes) {
     static const int mode = [] {
         const char* e = std::getenv("RT_HOST_REGISTER");
-        if (std::getenv("RT_NO_HOST_REGISTER") || (e && std::string(e) == "never")) return 0;
-        return (e && std::string(e) == "always") ? 2 : 1;
+        if (!e || std::getenv("RT_NO_HOST_REGISTER")) return 0;
+        return std::string(e) == "always" ? 2 : std::string(e) == "second" ? 1 : 0;
     }();
     if (mode == 0 || !host || bytes < kMinPinBytes) return false;
     std::lock_guard<std::mutex> lock(g_pin_mutex);
@@ -1042,6 +1048,7 @@ int rt_traverse_time(rt_scene_t scene, void* hip_stream, double* ms_out, uint64_
 
 int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats) {
     if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    std::lock_guard<std::recursive_mutex> host_lock(g_host_render_mutex);
     if (!scene || !params || !rgb8_out) return fail(RT_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(g_dev.device));
@@ -1094,6 +1101,7 @@ int rt_render(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out,
 // device -> host copy of a batch runs on a stream of its own while the next batch renders.
 int rt_render_frames(rt_scene_t scene, const RtRenderParams* params, int frames, uint8_t* rgb8_out, RtStats* stats) {
     if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    std::lock_guard<std::recursive_mutex> host_lock(g_host_render_mutex);
     if (!scene || !params || !rgb8_out) return fail(RT_ERR_INVALID, "NULL argument");
     if (frames < 1) return fail(RT_ERR_INVALID, "frames must be >= 1");
     if (params->part_count > 1) return fail(RT_ERR_INVALID, "rt_render_frames renders whole frames (use rt_render_frames_device for parts)");
@@ -1180,6 +1188,7 @@ int rt_render_frames(rt_scene_t scene, const RtRenderParams* params, int frames,
 // gathered over RCCL and rank 0 receives the assembled frame in host memory.
 int rt_render_gathered(rt_scene_t scene, const RtRenderParams* params, uint8_t* rgb8_out, RtStats* stats) {
     if (!g_dev.ready) return fail(RT_ERR_NOT_INIT, "rt_init() has not succeeded in this process");
+    std::lock_guard<std::recursive_mutex> host_lock(g_host_render_mutex);
     if (!scene || !params) return fail(RT_ERR_INVALID, "NULL argument");
     const int world = rt_comm_world(), rank = rt_comm_rank();
     const char* lb = std::getenv("RT_COMM_LOOPBACK");
