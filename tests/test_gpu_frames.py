@@ -199,3 +199,45 @@ def test_render_frames_into_host_memory(gpu):
     for f in range(18):   # deterministic sampling: every frame is the same picture up to the order of the FP64 additions
         mx, nd, _ = helpers.diff_stats(many[f], one)
         assert mx <= 1 and nd <= 0.002 * one.size, (f, mx, nd)
+
+
+@pytest.mark.gpu
+def test_host_buffer_calls_from_two_threads(gpu):
+    """rt_render and rt_render_frames work on the library's own stream, events and staging buffers; threads that render different
+    scenes into host memory at the same time queue up on the library's lock and get the frames a single thread gets."""
+    import threading
+    a = rt.Scene(workloads.bvh_stress_scene(20000, 640, 360))
+    fa, pa, _ = helpers.load_case("c1_shadows_fresnel")
+    b = rt.Scene(fa)
+    p = workloads.default_config().params(rng="seeded", seed=11)
+    want_a = a.render_frames(p, 5)
+    want_b = b.render(pa)
+    got, errors = {}, []
+
+    def run_a():
+        try:
+            for k in range(4):
+                got["a%d" % k] = a.render_frames(p, 5)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    def run_b():
+        try:
+            for k in range(8):
+                got["b%d" % k] = b.render(pa)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run_a), threading.Thread(target=run_b)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    a.close()
+    b.close()
+    assert not errors, errors
+    for k in range(4):
+        assert np.array_equal(got["a%d" % k], want_a), k
+    for k in range(8):   # accumulated frame: the order of the FP64 additions may move a value across a truncation boundary
+        mx, nd, _ = helpers.diff_stats(got["b%d" % k], want_b)
+        assert mx <= 1 and nd <= 0.002 * want_b.size, (k, mx, nd)
