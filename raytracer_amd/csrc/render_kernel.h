@@ -53,6 +53,11 @@ struct WavefrontWorkspace {
     size_t chunk_capacity = 0;           // chunks both arrays hold
     unsigned long long chunk_key[4] = {0, 0, 0, 0};   // scene, queue size and frame layout the record belongs to
     bool chunk_order_valid = false;
+    // Level sizes of the last one-chunk frame of a small scene rendered through this workspace (render_wavefront.hip: k_tail): the
+    // next frame of the same shape hands the levels from the first small one on to ONE launch.
+    unsigned level_sizes[24] = {};
+    unsigned long long level_key[4] = {0, 0, 0, 0};
+    bool level_sizes_valid = false;
 };
 void wavefront_workspace_free(WavefrontWorkspace& ws);
 

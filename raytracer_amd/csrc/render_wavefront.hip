@@ -241,6 +241,9 @@ struct QIn {                              // what a consumer kernel works throug
     unsigned shards, region;              // entries of shard r: [r * region + lo, r * region + min(hi, tail))
     unsigned lo, hi;
 };
+// A tail as it stands in L2, where the atomics that count into it are performed: k_tail reads tails its own workgroup has just
+// counted into, and a line of this CU's L1 may be older than that.
+__device__ __forceinline__ unsigned tail_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct BlockSpan {
     unsigned shard, origin;               // this workgroup's shard and the queue index of its entry 0
     unsigned begin, end, step;            // the workgroup's first entry (lane 0), the end of the shard's entries, entries between rounds
@@ -252,7 +255,7 @@ __device__ __forceinline__ BlockSpan block_span(const QIn& q, unsigned per = 1u)
     const unsigned k = q.counts ? q.shards : 1u;
     b.shard = blockIdx.x % k;
     const unsigned j = blockIdx.x / k, nb = gridDim.x / k;
-    const unsigned tail = q.counts ? min(q.counts[b.shard * kCountStride], q.region) : q.n;
+    const unsigned tail = q.counts ? min(tail_load(&q.counts[b.shard * kCountStride]), q.region) : q.n;
     b.origin = q.counts ? b.shard * q.region : 0u;
     b.end = min(tail, q.hi) * per;
     b.begin = q.lo * per + j * kBlock;
@@ -458,6 +461,7 @@ constexpr unsigned kNextStride = kFetchCounterWords / kXcds;   // counters 128 b
 constexpr unsigned kNextBase = 32;     // offset of the fetch counters in WavefrontWorkspace::counters
 constexpr unsigned kLevelCountBase = 4;   // two queue-size words of the levels enqueued without a host round trip
 constexpr unsigned kLevelTotal = 6;       // u64: rays of the levels whose size only the device knew (words 2 .. 7 are read back as one piece)
+constexpr unsigned kLevelSizeBase = 8, kLevelSizeWords = 24;   // small scenes: entries of the queue of level l, l < 24 (words 2 .. 31 are read back as one piece)
 __device__ __forceinline__ unsigned share_begin(unsigned n, unsigned q) {
     return q >= kXcds ? n : (unsigned)(((unsigned long long)n * q / kXcds) & ~63ull);
 }
@@ -980,13 +984,10 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
 // (Tracing the rays of a small scene inside this kernel instead of in k_traverse_small -- no hit records, one launch per
 // level less -- was built and measured: the kernel grows from 223 to 255 registers and C3 at 16 spp takes 47.6 instead of
 // 40.3 ms, C1 0.67 instead of 0.66 ms: the traversal loop runs better at its own 4 waves per SIMD than inside this kernel's 2.)
-template <int F, bool EMIT, bool SMALL>
-__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_TEX_WAVES : EMIT ? RT_SHADE_WAVES : RT_SHADE_LEAN_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
-                                                  const HitQ hits_all, const QIn in, const EmitCtx E, double* __restrict__ accum) {
-    __shared__ SceneStage<SMALL> staged;
-    const BlockSpan span = block_span(in);
-    if (span.begin >= span.end) return;
-    const DScene S = staged.stage(S0);
+// The work of one workgroup of k_shade on its span of a queue (a function of its own so that k_tail can run it level after level).
+template <int F, bool EMIT>
+__device__ __forceinline__ void shade_body(const DScene& S, const DParams& P, const RayQ& rays_all, const HitQ& hits_all, const QIn& in,
+                                           const BlockSpan& span, const EmitCtx& E, double* __restrict__ accum) {
     const int lane = threadIdx.x & 63;
     const RayQ rays = rebase(rays_all, span.origin);
     const HitQ hits{hits_all.p + span.origin, hits_all.stride};
@@ -1026,6 +1027,16 @@ __global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTUR
     }
 }
 
+template <int F, bool EMIT, bool SMALL>
+__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_TEXTURE | RT_FEAT_ENV)) ? RT_SHADE_TEX_WAVES : EMIT ? RT_SHADE_WAVES : RT_SHADE_LEAN_WAVES) k_shade(const DScene S0, const DParams P, const RayQ rays_all,
+                                                  const HitQ hits_all, const QIn in, const EmitCtx E, double* __restrict__ accum) {
+    __shared__ SceneStage<SMALL> staged;
+    const BlockSpan span = block_span(in);
+    if (span.begin >= span.end) return;
+    const DScene S = staged.stage(S0);
+    shade_body<F, EMIT>(S, P, rays_all, hits_all, in, span, E, accum);
+}
+
 // ------------------------------------------------------------------------------------------ k_shadow
 // One lane per shadow ray: lane i traces ray i % (2 x samples) of bundle i / (2 x samples) -- the first `samples` rays
 // belong to the diffuse evaluation of the light's visibility, the others to the specular one (shading.h:154,192) -- from
@@ -1045,13 +1056,10 @@ constexpr int kInlineSegments = 6;
 #ifndef RT_SHADOW_TEX_WAVES
 #define RT_SHADOW_TEX_WAVES 2     // ... of the analytic + textures variant
 #endif
+// The work of one workgroup of k_shadow on its share of the bundles (stack_lds: this lane's column of the traversal stack in LDS).
 template <int F, bool SMALL>
-__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_ENV)) ? RT_SHADOW_COMPLEX_WAVES : (F & RT_FEAT_TEXTURE) ? RT_SHADOW_TEX_WAVES : RT_SHADOW_WAVES)
-k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn in, const EmitCtx E0, double* __restrict__ accum,
-         unsigned long long* __restrict__ stats) {
-    __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
-    __shared__ SceneStage<SMALL> staged;
-    const DScene S = staged.stage(S0);
+__device__ __forceinline__ void shadow_body(const DScene& S, const DParams& P, const BundleQ& bundles_all, const QIn& in, const EmitCtx& E0,
+                                            double* __restrict__ accum, unsigned long long* __restrict__ stats, unsigned long long* stack_lds) {
     // The 2 x samples rays of a bundle towards a light of radius 0 are one and the same ray (shading.h:31-36 only moves the
     // target when the light has a size): it is traced ONCE, carries the sum of the weights and counts as the 2 x samples
     // closest-hit queries the reference makes.  With point lights only, a bundle is one lane; otherwise the other lanes of such
@@ -1065,13 +1073,13 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
     const int per_shift = (per & (per - 1u)) == 0u ? __builtin_ctz(per) : -1;
     // this workgroup's shard of the bundles (block_span in 64-bit lanes: a bundle is `per` lanes)
     const unsigned shard = blockIdx.x % in.shards;
-    const unsigned long long n = (unsigned long long)min(in.counts[shard * kCountStride], in.region) * per;
+    const unsigned long long n = (unsigned long long)min(tail_load(&in.counts[shard * kCountStride]), in.region) * per;
     const unsigned long long first = (unsigned long long)(blockIdx.x / in.shards) * kBlock, stride = (unsigned long long)(gridDim.x / in.shards) * kBlock;
     const BundleQ bundles{bundles_all.p + (size_t)shard * in.region, bundles_all.stride};
     const EmitCtx E = emit_view(E0, shard);   // a chain that goes on as a queued ray stays in the shard
     const int lane = threadIdx.x & 63;
     TravStack stack;
-    stack.lds = &stack_mem[0][threadIdx.x];
+    stack.lds = stack_lds;
     stack.stride = kBlock;
     Counters C{0u, 0u, 0u, 0u};
     unsigned coincident = 0u;   // queries of the reference that were not traced because they coincide with one that was
@@ -1191,33 +1199,24 @@ k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn 
     }
 }
 
+template <int F, bool SMALL>
+__global__ void __launch_bounds__(kBlock, (F & (RT_FEAT_COMPLEX | RT_FEAT_ENV)) ? RT_SHADOW_COMPLEX_WAVES : (F & RT_FEAT_TEXTURE) ? RT_SHADOW_TEX_WAVES : RT_SHADOW_WAVES)
+k_shadow(const DScene S0, const DParams P, const BundleQ bundles_all, const QIn in, const EmitCtx E0, double* __restrict__ accum,
+         unsigned long long* __restrict__ stats) {
+    __shared__ unsigned long long stack_mem[SMALL ? 1 : kTravLdsEntries + 1][kBlock];
+    __shared__ SceneStage<SMALL> staged;
+    const DScene S = staged.stage(S0);
+    shadow_body<F, SMALL>(S, P, bundles_all, in, E0, accum, stats, &stack_mem[0][threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------ k_traverse_small
 // k_traverse for scenes of at most kSmallScenePrims primitives: one lane per queued ray, every primitive tested in step
 // by the whole wave (closest_hit_small).  The persistent scheduling of k_traverse -- refill, votes, parked leaves, a
 // stack -- buys nothing when there is no hierarchy to speak of, and costs most of the time of such frames.
-#ifndef RT_SMALL_WAVES
-#define RT_SMALL_WAVES 4
-#endif
+// The work of one workgroup of k_traverse_small on its span of a queue.
 template <int F>
-__global__ void __launch_bounds__(kBlock, RT_SMALL_WAVES)
-k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const HitQ hits_all, const QIn in,
-                 unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total, unsigned* __restrict__ zero_a,
-                 unsigned* __restrict__ zero_b, const unsigned zero_shards) {
-    __shared__ SmallSceneLds small_lds;
-    // the tails this level's shading kernel counts into (next queue's shards, shadow bundles) start at zero: stores here
-    // instead of a fill launch each (the kernels of a stream run one after the other)
-    if (blockIdx.x == 0 && threadIdx.x < zero_shards) {
-        if (zero_a) zero_a[threadIdx.x * kCountStride] = 0u;
-        if (zero_b) zero_b[threadIdx.x * kCountStride] = 0u;
-    }
-    // a level whose size only the device knows joins the frame's ray total
-    if (in.counts && blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned t = queue_total(in);
-        if (t != 0u) atomicAdd(level_total, (unsigned long long)t);
-    }
-    const BlockSpan span = block_span(in);
-    if (span.begin >= span.end) return;   // (whole workgroup: before the barrier of the staging)
-    const DScene S = stage_small_scene(S0, small_lds);
+__device__ __forceinline__ void traverse_small_body(const DScene& S, const DParams& P, const RayQ& rays_all, const HitQ& hits_all, const BlockSpan& span,
+                                                    unsigned long long* __restrict__ counters) {
     const RayQ rays = rebase(rays_all, span.origin);
     const HitQ hits{hits_all.p + span.origin, hits_all.stride};
     const unsigned n = span.end;
@@ -1253,6 +1252,99 @@ k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const Hi
         for (int off = 32; off > 0; off >>= 1) prims += __shfl_down(prims, off);
         if (lane == 0 && prims != 0u) atomicAdd(&counters[2], (unsigned long long)prims);   // (idle waves of a nearly empty level stay off the counter)
     }
+}
+
+#ifndef RT_SMALL_WAVES
+#define RT_SMALL_WAVES 4
+#endif
+template <int F>
+__global__ void __launch_bounds__(kBlock, RT_SMALL_WAVES)
+k_traverse_small(const DScene S0, const DParams P, const RayQ rays_all, const HitQ hits_all, const QIn in,
+                 unsigned long long* __restrict__ counters, unsigned long long* __restrict__ level_total, unsigned* __restrict__ level_size,
+                 unsigned* __restrict__ zero_a, unsigned* __restrict__ zero_b, const unsigned zero_shards) {
+    __shared__ SmallSceneLds small_lds;
+    // the tails this level's shading kernel counts into (next queue's shards, shadow bundles) start at zero: stores here
+    // instead of a fill launch each (the kernels of a stream run one after the other)
+    if (blockIdx.x == 0 && threadIdx.x < zero_shards) {
+        if (zero_a) zero_a[threadIdx.x * kCountStride] = 0u;
+        if (zero_b) zero_b[threadIdx.x * kCountStride] = 0u;
+    }
+    // a level whose size only the device knows joins the frame's ray total, and its size the record of the frame's levels
+    if (in.counts && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned t = queue_total(in);
+        if (t != 0u) atomicAdd(level_total, (unsigned long long)t);
+        if (level_size) *level_size = t;
+    }
+    const BlockSpan span = block_span(in);
+    if (span.begin >= span.end) return;   // (whole workgroup: before the barrier of the staging)
+    const DScene S = stage_small_scene(S0, small_lds);
+    traverse_small_body<F>(S, P, rays_all, hits_all, span, counters);
+}
+
+// ------------------------------------------------------------------------------------------ k_tail
+// The deep levels of a small scene's ray tree in ONE launch.  A 1-spp frame of the default scene is a dozen levels of which all
+// but the first two hold a few thousand rays at most: three launches each, ~30 us per level in launch gaps and in grids of two
+// thousand workgroups that find nothing to do -- 330 of the C1 frame's 600 us.  The queues of a small scene are cut into K shards
+// and a wave emits into the shard its input came from, so the ray tree below a shard's entries never leaves the shard: workgroup
+// r of this kernel (grid = K) takes shard r through traversal, shading and shadow rays of level after level on its own, with
+// workgroup barriers between the phases and no synchronisation across workgroups at all; it stops when its shard runs empty.
+// The phases are the bodies of k_traverse_small, k_shade and k_shadow, the queues alternate between the two the host hands
+// over, and what the per-level kernels leave for the host (tails of the last level, ray total, level sizes, overflow flag) is
+// left the same way.  Whether and from which level a frame ends this way is decided by the host from the level sizes of the
+// previous frame of the same shape (Driver::tail_from): a guess that can only cost time, never a ray.
+struct TailArgs {
+    RayQ q[2];                  // level `first` reads q[0] and queues into q[1], the next level the other way round, ...
+    HitQ h[2];
+    BundleQ bundles;
+    unsigned* shard_counts;     // tails of level l: shard_counts + (l % kCountArrays) * kShards * kCountStride
+    unsigned* bundle_tails;
+    unsigned* overflow;
+    unsigned long long* level_total;
+    unsigned* level_sizes;      // [kLevelSizeWords]
+    uint8_t* direct;
+    unsigned region, bundle_region, shards;
+    int first, levels, shadows;
+};
+template <int F>
+__global__ void __launch_bounds__(kBlock, 2)
+k_tail(const DScene S0, const DParams P, const TailArgs A, double* __restrict__ accum, unsigned long long* __restrict__ stats) {
+    __shared__ SmallSceneLds lds;
+    __shared__ unsigned long long stack_mem[1][kBlock];
+    const DScene S = stage_small_scene(S0, lds);
+    const unsigned shard = blockIdx.x;   // gridDim.x == A.shards
+    unsigned* const my_bundle_tail = A.bundle_tails + shard * kCountStride;
+    int level = A.first;
+    for (; level < A.levels; ++level) {
+        unsigned* const tails_in = A.shard_counts + (size_t)(level % (int)kCountArrays) * kShards * kCountStride;
+        unsigned* const tails_out = A.shard_counts + (size_t)((level + 1) % (int)kCountArrays) * kShards * kCountStride;
+        const unsigned n_in = min(tail_load(&tails_in[shard * kCountStride]), A.region);   // the same number in every lane
+        if (threadIdx.x == 0) {
+            tails_out[shard * kCountStride] = 0u;
+            *my_bundle_tail = 0u;
+            if (n_in != 0u) {
+                atomicAdd(A.level_total, (unsigned long long)n_in);
+                if (level < (int)kLevelSizeWords) atomicAdd(&A.level_sizes[level], n_in);
+            }
+        }
+        if (n_in == 0u) break;
+        __syncthreads();   // the zeroes stand before anything is counted
+        const int k = (level - A.first) & 1;
+        const QIn in{tails_in, 0u, A.shards, A.region, 0u, 0xffffffffu};
+        const BlockSpan span = block_span(in);
+        traverse_small_body<F>(S, P, A.q[k], A.h[k], span, stats);
+        __syncthreads();   // hit records written, visible to the workgroup that wrote them
+        const EmitCtx E{A.q[k ^ 1], tails_out, A.overflow, A.region, A.direct, A.bundles, A.bundle_tails, A.bundle_region, A.shards};
+        shade_body<F, true>(S, P, A.q[k], A.h[k], in, span, E, accum);
+        __syncthreads();   // children and bundles queued and counted
+        if (A.shadows) {
+            const QIn bin{A.bundle_tails, 0u, A.shards, A.bundle_region, 0u, 0xffffffffu};
+            shadow_body<F, true>(S, P, A.bundles, bin, E, accum, stats, &stack_mem[0][threadIdx.x]);
+            __syncthreads();
+        }
+    }
+    // the host sums the tails of level `levels` and reads the level sizes: a shard that ran empty early leaves zeroes there
+    if (threadIdx.x == 0 && level < A.levels)
+        A.shard_counts[(size_t)(A.levels % (int)kCountArrays) * kShards * kCountStride + shard * kCountStride] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------ k_resolve
@@ -1420,7 +1512,8 @@ struct Driver {
         unsigned long long* level_total = reinterpret_cast<unsigned long long*>(ws.counters + kLevelTotal);
         if (small_scene()) {
             const unsigned blocks = in.counts ? grid_for(in, bound) : std::max(1u, std::min((bound + kBlock - 1) / kBlock, (unsigned)ws.compute_units * (unsigned)grid_blocks_per_cu));
-            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), in, ws.stats, level_total, zero_a, zero_b, K);
+            hipLaunchKernelGGL((k_traverse_small<F>), dim3(blocks), dim3(kBlock), 0, stream, S, P, rays(q, level), hits(q), in, ws.stats, level_total,
+                               level < (int)kLevelSizeWords ? ws.counters + kLevelSizeBase + level : nullptr, zero_a, zero_b, K);
             zero_a = zero_b = nullptr;
             return;
         }
@@ -1552,6 +1645,34 @@ struct Driver {
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, stream, tails(level), K, region(), ws.counters + kLevelCountBase);
     }
 
+    // k_tail: from which level on (0: not at all) the rest of this chunk's ray tree goes into one launch.  By the sizes the
+    // levels of the previous frame of this shape had: the first level from which every level would keep the K workgroups of
+    // k_tail busy for two rounds at most (8192 lanes a round; a shadow ray is a lane like a queued ray).  RT_NO_TAIL: A/B runs.
+    int tail_from(int levels, const unsigned long long key[4]) {
+        static const bool off = getenv("RT_NO_TAIL") != nullptr;
+        if (off || ws.fixed || !small_scene() || K <= 1 || !may_emit || !allow_grow || levels > (int)kLevelSizeWords || levels < 3) return 0;
+        if (!ws.level_sizes_valid || memcmp(key, ws.level_key, sizeof(ws.level_key)) != 0) return 0;
+        const unsigned long long lanes_per_ray = 1ull + (with_shadows() ? (unsigned long long)S.n_lights * 2ull * (unsigned)P.shadow_samples : 0ull);
+        int from = levels;
+        for (int l = levels - 1; l >= 1; --l) {
+            if ((unsigned long long)ws.level_sizes[l] * lanes_per_ray > 2ull * K * kBlock) break;
+            from = l;
+        }
+        return levels - from >= 2 ? from : 0;   // (one level is as well served by its own three launches)
+    }
+    template <int F> void launch_tail_variant(const TailArgs& A) {
+        hipLaunchKernelGGL((k_tail<F>), dim3(K), dim3(kBlock), 0, stream, S, P, A, accum, ws.stats);
+    }
+    void launch_tail(int q, int qo, int first, int levels) {
+        const TailArgs A{{rays(q), rays(qo)}, {hits(q), hits(qo)}, BundleQ{static_cast<rt_q4*>(ws.bundles), (unsigned)ws.capacity}, ws.shard_counts, bundle_tails(),
+                         ws.counters + 2, reinterpret_cast<unsigned long long*>(ws.counters + kLevelTotal), ws.counters + kLevelSizeBase, direct,
+                         region(), ws.bundles ? region() : 0u, K, first, levels, with_shadows() ? 1 : 0};
+        // one variant for the three phases: the shading kernel's, which covers what the traversal and shadow variants cover
+        if (variant == 0) launch_tail_variant<kSpheres>(A);
+        else if (variant == 1) launch_tail_variant<kAnalytic>(A);
+        else if (variant == 3) launch_tail_variant<kTextured>(A);
+        else launch_tail_variant<kFull>(A);
+    }
     // A whole ray tree without a host round trip per level: every level's queue size stays on the device (the kernels
     // of level L + 1 read the tails the shading kernel of level L left), grids are sized by what the host knows -- the
     // level cannot hold more than the previous level's bound times its fan-out, nor more than a queue -- and the queue
@@ -1560,11 +1681,17 @@ struct Driver {
     // level with batches (process()).  Returns 0 = done, 1 = overflow; rays still queued after `levels` levels (chains
     // of shadow segments through transmitting surfaces) are finished by process().
     int run_levels(int q, unsigned n0, int levels) {
-        // overflow flag, the word the last queue's size goes to, and the ray total start at zero (words 2 .. 7)
-        if (!ok(hipMemsetAsync(ws.counters + 2, 0, 6 * sizeof(unsigned), stream))) { release(q); return 0; }
+        // overflow flag, the word the last queue's size goes to, the ray total and the level sizes start at zero (words 2 .. 31)
+        if (!ok(hipMemsetAsync(ws.counters + 2, 0, (kLevelSizeBase + kLevelSizeWords - 2) * sizeof(unsigned), stream))) { release(q); return 0; }
         size_t bound = n0;
         int level = 0;
-        for (; level < levels && err == hipSuccess; ++level) {
+        const unsigned long long key[4] = {S.serial, ((unsigned long long)n0 << 32) | (unsigned)levels,
+                                           ((unsigned long long)P.width << 32) | (unsigned)(P.frames * P.part_rows),
+                                           (unsigned long long)P.shadows | (unsigned long long)P.fresnel << 1 | (unsigned long long)P.normals << 2 | (unsigned long long)P.use_bvh << 3 |
+                                               (unsigned long long)P.rng_mode << 4 | (unsigned long long)P.glossy_samples << 8 | (unsigned long long)P.shadow_samples << 16 |
+                                               (unsigned long long)P.max_bounces << 24 | (unsigned long long)P.spp << 32};
+        const int tail = tail_from(levels, key);
+        for (; level < (tail > 0 ? tail : levels) && err == hipSuccess; ++level) {
             const QIn in = level == 0 ? dense(n0) : sharded(level);
             const unsigned n = (unsigned)bound;
             const bool small = small_scene();
@@ -1581,18 +1708,34 @@ struct Driver {
             q = qo;
             bound = std::min<size_t>(ws.capacity, bound * fanout(level));
         }
+        if (tail > 0 && level == tail && err == hipSuccess) {   // the levels from `tail` on in one launch (k_tail)
+            const int qo = acquire();
+            if (qo >= 0) {
+                launch_tail(q, qo, tail, levels);
+                if (getenv("RT_DEBUG_LEVELS")) fprintf(stderr, "[rt levels] levels %d .. %d of %u primary rays in one launch (k_tail)\n", tail, levels - 1, n0);
+                if ((levels - tail) & 1) { release(q); q = qo; } else release(qo);   // the queue the last level queued into
+                level = levels;
+            }
+        }
         // (looking every third level whether anything is still queued was measured: a round trip costs ~70 us with the
         // launches behind it, more than the empty levels of a C1 frame save)
-        unsigned local[6] = {0, 0, 0, 0, 0, 0};
-        unsigned* res = ws.host_readback ? ws.host_readback : local;   // words 2 .. 7 of the counters, read back as one piece
+        constexpr unsigned kReadWords = kLevelSizeBase + kLevelSizeWords - 2;
+        unsigned local[kReadWords] = {};
+        unsigned* res = (ws.host_readback && ws.fixed) ? ws.host_readback : local;   // words 2 .. 31 of the counters, read back as one piece
+        const unsigned read_words = ws.fixed ? 6u : kReadWords;                      // (the fixed workspace's pinned words hold the first six)
         unsigned queued = 0, overflowed = 0;
         unsigned long long total = 0;
         if (err == hipSuccess) {
             sum_tails(level);
-            if (ok(hipMemcpyAsync(res, ws.counters + 2, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) && ok(hipStreamSynchronize(stream))) {
+            if (ok(hipMemcpyAsync(res, ws.counters + 2, read_words * sizeof(unsigned), hipMemcpyDeviceToHost, stream)) && ok(hipStreamSynchronize(stream))) {
                 overflowed = res[0];
                 queued = res[kLevelCountBase - 2];
                 memcpy(&total, &res[kLevelTotal - 2], sizeof(total));
+                if (!ws.fixed && !overflowed && small_scene() && K > 1 && allow_grow && levels <= (int)kLevelSizeWords) {   // the record for the next frame of this shape
+                    memcpy(ws.level_sizes, &res[kLevelSizeBase - 2], sizeof(ws.level_sizes));
+                    memcpy(ws.level_key, key, sizeof(key));
+                    ws.level_sizes_valid = true;
+                }
             }
         }
         if (err != hipSuccess) { release(q); return 0; }
