@@ -288,6 +288,7 @@ struct HostArrays {
     int32_t features = 0;
     int32_t spawning_materials = 0;
     int32_t transparent_materials = 0;
+    int32_t area_lights = 0;
     DCamera cam{};
 };
 
@@ -370,6 +371,7 @@ static HostArrays derive_arrays(const RtSceneDesc& d, const HostBvh& bvh) {
         std::memcpy(h.lights[i].pos, d.lights[i].position, 24);
         std::memcpy(h.lights[i].intensity, d.lights[i].intensity, 24);
         h.lights[i].radius = d.lights[i].radius;
+        if (d.lights[i].radius != 0.0) h.area_lights = 1;
     }
     if (d.env.present) h.features |= RT_FEAT_ENV;
     // camera.cpp:27-86
@@ -705,6 +707,7 @@ int rt_scene_create(const RtSceneDesc* desc, rt_scene_t* out) {
     d.features = h.features;
     d.spawning_materials = h.spawning_materials;
     d.transparent_materials = h.transparent_materials;
+    d.area_lights = h.area_lights;
     for (int a = 0; a < 3; ++a) { d.root_lo[a] = b32.root_lo[a]; d.root_hi[a] = b32.root_hi[a]; }
     d.shutter_time = desc->shutter_time;
     d.cam = h.cam;

@@ -146,6 +146,8 @@ struct DScene {
     float root_lo[3], root_hi[3];   // widened like the node boxes
     int32_t spawning_materials;     // 1 when some material reflects or transmits (secondary radiance rays possible)
     int32_t transparent_materials;  // 1 when some material transmits (shadow rays then need their CLOSEST occluder)
+    int32_t area_lights;            // 1 when some light has a radius (else the shadow rays of a hit towards a light coincide: one lane per bundle)
+    int32_t reserved0;
     double shutter_time;
     DCamera cam;
     uint64_t serial;                // identifies the scene inside this process (host bookkeeping only)

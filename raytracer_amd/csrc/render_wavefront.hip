@@ -1652,7 +1652,8 @@ struct Driver {
         static const bool off = getenv("RT_NO_TAIL") != nullptr;
         if (off || ws.fixed || !small_scene() || K <= 1 || !may_emit || !allow_grow || levels > (int)kLevelSizeWords || levels < 3) return 0;
         if (!ws.level_sizes_valid || memcmp(key, ws.level_key, sizeof(ws.level_key)) != 0) return 0;
-        const unsigned long long lanes_per_ray = 1ull + (with_shadows() ? (unsigned long long)S.n_lights * 2ull * (unsigned)P.shadow_samples : 0ull);
+        const unsigned long long per = (S.area_lights || P.trace_coincident) ? 2ull * (unsigned)P.shadow_samples : 1ull;   // lanes of a bundle in k_shadow
+        const unsigned long long lanes_per_ray = 1ull + (with_shadows() ? (unsigned long long)S.n_lights * per : 0ull);
         int from = levels;
         for (int l = levels - 1; l >= 1; --l) {
             if ((unsigned long long)ws.level_sizes[l] * lanes_per_ray > 2ull * K * kBlock) break;
@@ -1735,6 +1736,11 @@ struct Driver {
                     memcpy(ws.level_sizes, &res[kLevelSizeBase - 2], sizeof(ws.level_sizes));
                     memcpy(ws.level_key, key, sizeof(key));
                     ws.level_sizes_valid = true;
+                    if (getenv("RT_DEBUG_LEVELS")) {
+                        fprintf(stderr, "[rt levels] sizes:");
+                        for (int l = 1; l < levels; ++l) fprintf(stderr, " %u", ws.level_sizes[l]);
+                        fprintf(stderr, "\n");
+                    }
                 }
             }
         }
