@@ -37,15 +37,31 @@ def test_frames_after_the_first_end_in_one_launch_and_equal_it(gpu, name, capfd,
 
 
 @pytest.mark.gpu
-def test_tail_with_seeded_sampling_and_many_frames_per_call(gpu):
-    """Seeded frames (the tail's phases draw from the rays' own streams, so the pictures are reproducible) and 16 frames per
-    call, whose levels are 16 times as large."""
+def test_tail_with_seeded_sampling_and_many_frames_per_call(gpu, capfd, monkeypatch):
+    """Seeded frames (the tail's phases draw from the rays' own streams, so the pictures are reproducible), and 16 frames per
+    call, whose levels are 16 times as large and whose record is kept apart from the single frames'."""
+    monkeypatch.setenv("RT_DEBUG_LEVELS", "1")
     scene_file, params, hi, lo, floor = helpers.load_stochastic("st_soft_shadows", 16, seed=1000)
     scene = rt.Scene(scene_file)
     a = scene.render(params)
     b = scene.render(params)
     c = scene.render(params)
-    scene.close()
     for img in (b, c):
         mx, nd, _ = helpers.diff_stats(img, a)
         assert mx <= 1 and nd <= 0.002 * a.size, (mx, nd)
+    scene.close()
+    scene_file, params, golden = helpers.load_case("c1_shadows_fresnel")
+    params.rng_mode, params.seed = rt.RT_RNG_SEEDED, 77
+    scene = rt.Scene(scene_file)
+    first = scene.render_frames(params, 16).copy()
+    capfd.readouterr()
+    again = scene.render_frames(params, 16)
+    err = capfd.readouterr().err
+    single = scene.render(params)
+    scene.close()
+    assert "k_tail" in err, err[-300:]
+    for f in range(16):
+        mx, nd, _ = helpers.diff_stats(again[f], first[f])
+        assert mx <= 1 and nd <= 0.002 * first[f].size, (f, mx, nd)
+    mx, nd, _ = helpers.diff_stats(single, first[0])
+    assert mx <= 1 and nd <= 0.002 * single.size, (mx, nd)
