@@ -657,6 +657,10 @@ __device__ __forceinline__ RayF make_rayf(const Ray& r) {
 // t = B * inv - o * inv with one FMA per plane; the extra rounding of o*inv is of the size of the origin's own FP32
 // rounding, which the host pad covers four times over.  min/max order the two planes of an axis (no sign select).
 // For an exactly axis-parallel ray (inv = +-inf) both products are NaN and the axis simply does not constrain.
+// SLACK = false: the caller's box carries the host pad of the node boxes (host_bvh.cpp: node4_pad), which covers the relative
+// roundings as plane displacements too -- |plane - o| is bounded by twice the scene's extent -- so that, as in node4_test, the two
+// slack operations per interval end are left out (the per-primitive boxes of small scenes: four instructions of twenty-one).
+template <bool SLACK = true>
 __device__ __forceinline__ bool box_test32(const float* lo, const float* hi, const RayF& f, float tmin, float tmax, float& entry) {
     constexpr float kSlack = 9.53674316e-7f;  // 2^-20
     const float ax = fmaf(lo[0], f.inv[0], -f.oi[0]), bx = fmaf(hi[0], f.inv[0], -f.oi[0]);
@@ -664,8 +668,10 @@ __device__ __forceinline__ bool box_test32(const float* lo, const float* hi, con
     const float az = fmaf(lo[2], f.inv[2], -f.oi[2]), bz = fmaf(hi[2], f.inv[2], -f.oi[2]);
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    tn = fmaf(-fabsf(tn), kSlack, tn);
-    tf = fmaf(fabsf(tf), kSlack, tf);
+    if (SLACK) {
+        tn = fmaf(-fabsf(tn), kSlack, tn);
+        tf = fmaf(fabsf(tf), kSlack, tf);
+    }
     tn = fmaxf(tn, tmin);   // a NaN interval end falls back to the ray's own range
     tf = fminf(tf, tmax);
     entry = tn;
@@ -696,7 +702,7 @@ __device__ __forceinline__ bool closest_hit_small(const DScene& S, const DParams
         if (S.prim_boxes) {
             float e;
             if (P.count_tests) C.nodes += live ? 1u : 0u;
-            enters = live && box_test32(S.prim_boxes + 6 * prim, S.prim_boxes + 6 * prim + 3, rf, tmin32, tmax32, e);
+            enters = live && box_test32<false>(S.prim_boxes + 6 * prim, S.prim_boxes + 6 * prim + 3, rf, tmin32, tmax32, e);
         }
         if (__ballot(enters) == 0ull) continue;
         if (enters) {
