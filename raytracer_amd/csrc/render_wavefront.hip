@@ -939,9 +939,9 @@ __device__ __forceinline__ bool shade_ray(const DScene& S, const DParams& P, con
         D3 Hv = normalize(Ld + V);
         double hdn = smax(0.0, dot(Hv, N));
         // shading.h:206, fast_pow :177.  A material without a specular colour multiplies the power by zero: where the power is
-        // certain to be a finite number (0 <= hdn, 0 < shininess < inf: the exponent is -inf or finite) any finite factor gives
+        // certain to be a finite number (0 <= hdn <= 1 + a few ulp, 0 < shininess < 1e12: the exponent is -inf or a finite number below 1) any finite factor gives
         // the same product, bit for bit, and the two transcendental functions are left out (matte floors are most of the hits).
-        const bool matte = M.specular[0] == 0.0 && M.specular[1] == 0.0 && M.specular[2] == 0.0 && M.shininess > 0.0 && M.shininess < 1e300 && hdn >= 0.0;
+        const bool matte = M.specular[0] == 0.0 && M.specular[1] == 0.0 && M.specular[2] == 0.0 && M.shininess > 0.0 && M.shininess < 1e12 && hdn >= 0.0;
         const double power = matte ? 1.0 : exp(M.shininess * log(hdn));
         D3 sp = cmul(ld3(M.specular), I) * power;
         if (!EMIT || !P.shadows) {  // visibility (1,1,1), shading.h:80
