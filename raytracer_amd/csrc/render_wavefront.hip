@@ -1544,7 +1544,8 @@ struct Driver {
     // launch, or null (none yet, another queue since, RT_NO_CHUNK_ORDER); *cost: where this launch records.
     bool chunk_history(unsigned n, bool size_on_device, int level, const unsigned** order, unsigned** cost) {
         static const bool off = getenv("RT_NO_CHUNK_ORDER") != nullptr;
-        if (off || ws.fixed || level != 0 || size_on_device || n < 65536u || n % (unsigned)RT_CHUNK != 0u) return false;
+        // (launches of many frames have their tail amortised already, and sorting half a million chunks costs them 125 us)
+        if (off || ws.fixed || level != 0 || size_on_device || n < 65536u || n > (1u << 22) || n % (unsigned)RT_CHUNK != 0u) return false;
         if ((long long)chunk.rows * P.width * chunk.ns != (long long)n || chunk.rows != P.frames * P.part_rows || chunk.ns != P.spp) return false;   // not the whole launch
         const unsigned chunks = n / (unsigned)RT_CHUNK;
         const unsigned long long key[4] = {S.serial, ((unsigned long long)n << 32) | (unsigned)P.frames, ((unsigned long long)P.part_index << 32) | (unsigned)P.part_count,
